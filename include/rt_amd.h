@@ -1,0 +1,149 @@
+/* include/rt_amd.h — C-ABI of the MI355X-native path tracer (librt_amd.so).
+ *
+ * Drop-in boundary for the per-pixel sample loop of 4meame/RayTracingInRust.  The reference has
+ * no FFI/plugin interface of its own (one binary, `fn main`, src/main.rs:577); the seam is the
+ * per-pixel closure src/main.rs:811-830 + `format_color` src/main.rs:832.  A Rust `main.rs`
+ * keeps its scene functions and camera set-up, mirrors them through the builder entry points
+ * below (one entry point per reference constructor, cited next to each), and replaces the
+ * `for j / for i / into_par_iter().map().sum()` loop nest with ONE call to rt_render(); see
+ * INTEGRATION.md for the `extern "C"` block.
+ *
+ * Conventions: plain C, no torch / HIP types.  Handles are small non-negative ints scoped to one
+ * rt_scene; every function that can fail returns a negative value (builders) or non-zero status
+ * (render) and leaves a message for rt_last_error().  The reference's failure mode is panic
+ * (src/bvh.rs:28,55,61; src/hit.rs:95; src/main.rs:431) — an error code here.  All reals are f64,
+ * as in the reference (src/vec.rs:10-12).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_scene rt_scene;
+typedef struct rt_rng rt_rng;
+
+/* enum Plane, src/rect.rs:9-13;  enum Axis, src/rotate.rs:8-12 */
+enum { RT_PLANE_XY = 0, RT_PLANE_XZ = 1, RT_PLANE_YZ = 2 };
+enum { RT_AXIS_X = 0, RT_AXIS_Y = 1, RT_AXIS_Z = 2 };
+
+/* Camera::new arguments, src/camera.rs:19 */
+typedef struct rt_camera {
+    double lookfrom[3], lookat[3], vup[3];
+    double vfov, aspect, aperture, focus_dist, time0, time1;
+} rt_camera;
+
+/* render flags */
+enum {
+    RT_F64 = 0,            /* reference precision (default): every operation in f64                         */
+    RT_F32 = 1,            /* throughput variant: f32 arithmetic (statistical parity only)                   */
+    RT_STOP_ON_ZERO = 2    /* opt-in: end a path whose throughput is exactly (0,0,0); differs from the
+                              reference only where a later bounce would have produced NaN (0*NaN)            */
+};
+
+const char* rt_last_error(void);
+/* number of visible HIP devices (0 without a GPU; never fails) */
+int rt_device_count(void);
+
+/* ---- seeded stream replacing rand::thread_rng() for HOST-side scene construction
+ *      (src/main.rs:154,457; src/perlin.rs:5,22).  Spec: raytracinginrust_amd/csrc/rt_rng.h          */
+rt_rng* rt_rng_create(uint64_t seed, uint32_t stream);
+void rt_rng_destroy(rt_rng*);
+double rt_rng_f64(rt_rng*);                       /* rng.gen::<f64>()                 */
+double rt_rng_range(rt_rng*, double a, double b); /* rng.gen_range(a..b)              */
+int rt_rng_bool(rt_rng*);                         /* rng.gen::<bool>()                */
+uint32_t rt_rng_index(rt_rng*, uint32_t n);       /* rng.gen_range(0..n)              */
+uint32_t rt_rng_u32(rt_rng*);
+void rt_rng_path(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t state_out[4]);
+
+/* ---- scene ------------------------------------------------------------------------------- */
+rt_scene* rt_scene_create(void);
+void rt_scene_destroy(rt_scene*);
+const char* rt_scene_error(rt_scene*);
+
+/* textures, src/texture.rs:16,37,63,90 */
+int rt_texture_constant(rt_scene*, const double rgb[3]);              /* ConstantTexture::new  */
+int rt_texture_check(rt_scene*, int odd, int even);                   /* CheckTexture::new     */
+int rt_texture_noise(rt_scene*, double scale, rt_rng* rng);           /* NoiseTexture::new (Perlin::new draws from rng, src/perlin.rs:67-75) */
+int rt_texture_image(rt_scene*, const uint8_t* rgb8, uint32_t width, uint32_t height);   /* ImageTexture::new */
+
+/* materials, src/mat.rs:205,260,303,383,410 */
+int rt_material_lambertian(rt_scene*, int texture);
+int rt_material_metal(rt_scene*, const double albedo[3], double fuzz);
+int rt_material_dielectric(rt_scene*, double index_of_refraction);
+int rt_material_diffuse_light(rt_scene*, int texture);
+int rt_material_isotropic(rt_scene*, int texture);
+
+/* hittables */
+int rt_sphere(rt_scene*, const double center[3], double radius, int material);                         /* Sphere::new, src/sphere.rs:46        */
+int rt_moving_sphere(rt_scene*, const double c0[3], const double c1[3], double t0, double t1,
+                     double radius, int material);                                                     /* MovingSphere::new, src/sphere.rs:133 */
+int rt_aarect(rt_scene*, int plane, double a0, double a1, double b0, double b1, double k, int material); /* AARect::new, src/rect.rs:35         */
+int rt_cube(rt_scene*, const double min[3], const double max[3], int material);                        /* Cube::new, src/cube.rs:14            */
+int rt_triangle(rt_scene*, const double v[9], int material);                                           /* Triangle::new, src/tri.rs:15         */
+int rt_list_create(rt_scene*);                                                                         /* HittableList::default, src/hit.rs:46 */
+int rt_list_push(rt_scene*, int list, int hittable);                                                   /* HittableList::push, src/hit.rs:52    */
+int rt_mesh(rt_scene*, const double* positions, uint32_t n_positions, const uint32_t* indices,
+            uint32_t n_indices, int material);                       /* Mesh::new, src/mesh.rs:16 — returns the `tris` HittableList */
+int rt_flip_normal(rt_scene*, int hittable);                                                           /* FlipNormal::new, src/hit.rs:105      */
+int rt_translate(rt_scene*, int hittable, const double offset[3]);                                     /* Translate::new, src/translate.rs:13  */
+int rt_rotate(rt_scene*, int axis, int hittable, double angle_deg);                                    /* Rotate::new, src/rotate.rs:32        */
+int rt_constant_medium(rt_scene*, int boundary, double density, int texture);                          /* ConstantMedium::new, src/medium.rs:17 */
+int rt_bvh(rt_scene*, const int* hittables, uint32_t n, double time0, double time1);                   /* BVH::new, src/bvh.rs:18              */
+int rt_bvh_of_list(rt_scene*, int list, double time0, double time1);                                   /* BVH::new(list.list, ..), src/main.rs:442 */
+
+/* the (world, lights) pair every scene fn returns, src/main.rs:153,278,348,453 */
+int rt_scene_set_world(rt_scene*, int hittable);
+int rt_lights_push(rt_scene*, int hittable);
+
+/* ---- host-side pieces of the boundary ------------------------------------------------------ */
+/* Camera::new, src/camera.rs:19-49: origin, lower_left_corner, horizontal, vertical, cu, cv (3 each),
+ * lens_radius, time0, time1 */
+void rt_camera_fields(const rt_camera*, double out21[21]);
+/* Vec3::format_color, src/vec.rs:125-131 (NaN -> 0, +inf -> 255) */
+void rt_format_color(const double rgb_sum[3], uint64_t samples_per_pixel, uint64_t out3[3]);
+/* PPM emitter, src/main.rs:767-769,832: "P3\nW H\n255\n" then one "r g b" line per pixel, rows top to
+ * bottom.  rgb_sum is W*H*3 in output order (row 0 = top).  path NULL or "-" writes to stdout. */
+int rt_write_ppm(const char* path, const double* rgb_sum, uint32_t W, uint32_t H, uint64_t samples_per_pixel);
+
+/* Flatten the Hittable tree into the device scene (no GPU needed); fills counts for inspection:
+ * objects, ops, rects, spheres, moving spheres, triangles, bvh nodes, materials, textures, lights, media, perlins */
+int rt_scene_flatten(rt_scene*, uint32_t counts_out[12]);
+
+/* ---- the hot path: replaces src/main.rs:772-833 -------------------------------------------- */
+/* Renders the whole frame on the current HIP device and returns, per pixel, the SUM over samples of
+ * ray_color (what `.sum()` yields at src/main.rs:830) as W*H*3 doubles in output order (row 0 = top,
+ * i.e. j = H-1).  Fails (non-zero) if no GPU/HIP device is present: there is no CPU fallback. */
+int rt_render(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
+              uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
+              double* rgb_sum_out);
+
+/* Tile-sharded form for one-process-per-GPU use.  The image's W*H pixels (output order) are cut into
+ * tiles of `tile_px` consecutive pixels; this call renders tiles t with t % world_size == rank into
+ * d_out (DEVICE pointer, n_local_tiles * tile_px * 3 doubles, tile-major; pixels past W*H are zero),
+ * asynchronously on `hip_stream` (a hipStream_t, may be NULL).  n_local_tiles =
+ * rt_local_tiles(W,H,tile_px,rank,world_size) is the same on every rank (padded), so a plain gather
+ * reassembles the frame. */
+uint32_t rt_local_tiles(uint32_t W, uint32_t H, uint32_t tile_px, uint32_t rank, uint32_t world_size);
+int rt_render_device(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
+                     uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
+                     uint32_t tile_px, uint32_t rank, uint32_t world_size,
+                     void* d_out, size_t d_out_bytes, void* hip_stream);
+/* Milliseconds of the most recent path-tracing kernel launched by this library on this thread's scene,
+ * from HIP events recorded on the launch stream (blocks until that kernel finishes). */
+int rt_last_kernel_ms(rt_scene*, float* ms_out);
+/* Counters of the most recent finished launch: [0] samples whose radiance was not finite (the reference's
+ * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
+ * that carried a live path ([2] / (64*[1]) = lane utilisation). */
+int rt_last_stats(rt_scene*, unsigned long long out3[3]);
+/* Debug/parity aid: like rt_render but also returns every sample's radiance (W*H*spp*3 doubles). */
+int rt_render_samples(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
+                      uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
+                      double* rgb_sum_out, double* samples_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,1154 @@
+// oracle/oracle.cpp
+//
+// *** TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this
+// library, and only as the checker / the reported CPU baseline.  The product path
+// (raytracinginrust_amd/) never includes, links or calls anything in this directory.
+//
+// What this is: a CPU restatement, in plain C++17 / f64, of the per-pixel sample loop of
+// 4meame/RayTracingInRust (reference mounted read-only at /root/reference): `ray_color`
+// over the Hittable tree with Lambertian / Metal / Dielectric / DiffuseLight / Isotropic
+// materials and mixture-PDF importance sampling.  It keeps the reference's object model
+// (trait objects -> virtual classes, recursion -> recursion) and its floating-point
+// expression order so that it can serve as the bit-level statement of "what the
+// reference computes" given a random stream.  Every function cites the reference
+// file:line it follows.  Compile with -ffp-contract=off (see oracle/Makefile): rustc
+// never fuses a*b+c.
+//
+// *** PARITY UNPINNED ***  The reference has no tests, no golden vectors and no fixed
+// RNG seed (every draw is rand::thread_rng(), OS-seeded), and it is Rust, which cannot be
+// built in this environment (no rustc/cargo, 70 unvendored crates, no network), so no
+// reference output exists to pin this restatement against.  The only known-answer data in
+// the reference is the six-row get_sphere_uv table in a comment (src/sphere.rs:12-17),
+// which tests/test_oracle_kat.py checks.  Beyond that the oracle is pinned by closed-form
+// KATs and estimator invariants (tests/test_oracle_*.py), not by the reference itself.
+//
+// Stated deviations from the reference (all forced):
+//   D1  RNG: one xoshiro128++ stream per (seed, pixel, sample) (oracle/orc_rng.h) instead
+//       of thread_rng(); draw kinds/order follow SURVEY.md Appendix A.
+//   D2  Empty `lights` list: the reference panics (src/hit.rs:94-96 unwrap on empty
+//       choose) / yields NaN (src/hit.rs:90-92).  Here: cosine-only sampling
+//       (direction = cosine.generate(), pdf = cosine.value()), no bool draw.
+//   D3  The per-pixel sum over samples is sequential s = 0..spp-1 (the reference's rayon
+//       tree sum, src/main.rs:811-830, has no defined order).
+//   D4  I(n) (uniform index) uses a widening multiply without rand's rejection step.
+//
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <cstdlib>
+#include <vector>
+#include <memory>
+#include <algorithm>
+#include <limits>
+#include <thread>
+#include <atomic>
+#include <string>
+#include <chrono>
+#include "orc_rng.h"
+
+namespace orc {
+
+static const double PI = 3.14159265358979323846264338327950288;  // std::f64::consts::PI
+static const double F64_MAX = std::numeric_limits<double>::max();
+static const double F64_INF = std::numeric_limits<double>::infinity();
+
+// Event counters for the algorithmic-bytes model.
+struct Counters {
+    uint64_t samples = 0, world_hits = 0, bvh_nodes = 0, rect_tests = 0, sphere_tests = 0,
+             msphere_tests = 0, tri_tests = 0, xforms = 0, medium_tests = 0, shades = 0,
+             light_pdf = 0, light_random = 0, texels = 0, perlin_evals = 0, nonfinite = 0,
+             bounces = 0;
+    static constexpr int N = 16;
+    void add(const Counters& o) {
+        uint64_t* a = &samples; const uint64_t* b = &o.samples;
+        for (int i = 0; i < N; i++) a[i] += b[i];
+    }
+};
+
+// thread_rng() stand-in + counters, threaded through every call that draws in the reference.
+struct Sampler {
+    Rng rng;
+    Counters c;
+};
+
+// Rust float semantics helpers
+static inline double f_max(double a, double b) { return std::fmax(a, b); }   // f64::max ignores NaN
+static inline double f_min(double a, double b) { return std::fmin(a, b); }
+static inline double f_clamp(double x, double lo, double hi) {               // f64::clamp keeps NaN
+    if (x < lo) return lo;
+    if (x > hi) return hi;
+    return x;
+}
+static inline uint64_t as_u64(double x) {                                    // saturating `as u64`
+    if (!(x > 0.0)) return 0;                      // NaN, negatives, zero
+    if (x >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)x;
+}
+
+// ---------------------------------------------------------------- src/vec.rs
+struct Vec3 {
+    double e[3];
+    Vec3() : e{0, 0, 0} {}
+    Vec3(double a, double b, double c) : e{a, b, c} {}
+    double x() const { return e[0]; }
+    double y() const { return e[1]; }
+    double z() const { return e[2]; }
+    double operator[](int i) const { return e[i]; }
+    double& operator[](int i) { return e[i]; }
+    // vec.rs:38-40
+    double dot(const Vec3& o) const { return e[0] * o.e[0] + e[1] * o.e[1] + e[2] * o.e[2]; }
+    // vec.rs:42-44
+    double length() const { return std::sqrt(dot(*this)); }
+    // vec.rs:46-54
+    Vec3 cross(const Vec3& o) const {
+        return Vec3(e[1] * o.e[2] - e[2] * o.e[1], e[2] * o.e[0] - e[0] * o.e[2], e[0] * o.e[1] - e[1] * o.e[0]);
+    }
+    Vec3 normalized() const;   // vec.rs:56-58
+    // vec.rs:112-114: self + (-self.dot(normal) * 2.0 * normal)
+    Vec3 reflect(const Vec3& n) const;
+    // vec.rs:116-121
+    Vec3 refract(const Vec3& n, double etai_over_etat) const;
+};
+typedef Vec3 Point3;
+typedef Vec3 Color;
+static inline Vec3 operator+(const Vec3& a, const Vec3& b) { return Vec3(a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2]); }
+static inline Vec3 operator-(const Vec3& a, const Vec3& b) { return Vec3(a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2]); }
+static inline Vec3 operator*(const Vec3& a, double s) { return Vec3(a.e[0] * s, a.e[1] * s, a.e[2] * s); }
+static inline Vec3 operator*(double s, const Vec3& a) { return Vec3(s * a.e[0], s * a.e[1], s * a.e[2]); }
+static inline Vec3 operator*(const Vec3& a, const Vec3& b) { return Vec3(a.e[0] * b.e[0], a.e[1] * b.e[1], a.e[2] * b.e[2]); }
+static inline Vec3 operator/(const Vec3& a, double s) { return Vec3(a.e[0] / s, a.e[1] / s, a.e[2] / s); }
+inline Vec3 Vec3::normalized() const { return *this / length(); }
+inline Vec3 Vec3::reflect(const Vec3& n) const { return *this + ((-dot(n)) * 2.0 * n); }
+inline Vec3 Vec3::refract(const Vec3& n, double etai_over_etat) const {
+    double cos_theta = f_min(((-1.0) * *this).dot(n), 1.0);
+    Vec3 r_out_perp = etai_over_etat * (*this + cos_theta * n);
+    double l = r_out_perp.length();
+    Vec3 r_out_para = ((-1.0) * std::sqrt(std::fabs(1.0 - l * l))) * n;
+    return r_out_perp + r_out_para;
+}
+// vec.rs:70-76
+static inline Vec3 vec3_random(Sampler& s, double lo, double hi) {
+    double a = s.rng.range(lo, hi), b = s.rng.range(lo, hi), c = s.rng.range(lo, hi);
+    return Vec3(a, b, c);
+}
+// vec.rs:78-85
+static inline Vec3 random_in_unit_sphere(Sampler& s) {
+    for (;;) {
+        Vec3 v = vec3_random(s, -1.0, 1.0);
+        if (v.length() < 1.0) return v;
+    }
+}
+// vec.rs:96-105
+static inline Vec3 random_in_unit_disk(Sampler& s) {
+    for (;;) {
+        double a = s.rng.range(-1.0, 1.0), b = s.rng.range(-1.0, 1.0);
+        Vec3 p(a, b, 0.0);
+        if (p.length() < 1.0) return p;
+    }
+}
+// vec.rs:125-131  (returns the three 8-bit values instead of a String)
+static inline void format_color(const Vec3& c, uint64_t spp, uint64_t out[3]) {
+    for (int k = 0; k < 3; k++) out[k] = as_u64(256.0 * f_clamp(std::sqrt(c[k] / (double)spp), 0.0, 0.999));
+}
+
+// ---------------------------------------------------------------- src/ray.rs
+struct Ray {
+    Point3 orig; Vec3 dir; double tm;
+    Ray() : tm(0) {}
+    Ray(const Point3& o, const Vec3& d, double t) : orig(o), dir(d), tm(t) {}
+    Point3 origin() const { return orig; }
+    Vec3 direction() const { return dir; }
+    Point3 at(double t) const { return orig + t * dir; }          // ray.rs:26-28
+    double time() const { return tm; }
+};
+
+// ---------------------------------------------------------------- src/onb.rs
+struct ONB {
+    Vec3 axis[3];
+    static ONB build_from_w(const Vec3& n) {                        // onb.rs:8-20
+        ONB o;
+        Vec3 w = n.normalized();
+        Vec3 a = (std::fabs(w.x()) > 0.9) ? Vec3(0.0, 1.0, 0.0) : Vec3(1.0, 0.0, 0.0);
+        Vec3 v = w.cross(a).normalized();
+        Vec3 u = w.cross(v);
+        o.axis[0] = u; o.axis[1] = v; o.axis[2] = w;
+        return o;
+    }
+    Vec3 u() const { return axis[0]; }
+    Vec3 v() const { return axis[1]; }
+    Vec3 w() const { return axis[2]; }
+    Vec3 local(const Vec3& a) const { return a.x() * u() + a.y() * v() + a.z() * w(); }   // onb.rs:34-36
+};
+
+// ---------------------------------------------------------------- src/aabb.rs
+struct AABB {
+    Vec3 min, max;
+    AABB() {}
+    AABB(const Vec3& a, const Vec3& b) : min(a), max(b) {}
+    bool hit(const Ray& r, double t_in, double t_out) const {       // aabb.rs:19-36
+        for (int a = 0; a < 3; a++) {
+            double inv_d = 1.0 / r.direction()[a];
+            double t0 = (min[a] - r.origin()[a]) * inv_d;
+            double t1 = (max[a] - r.origin()[a]) * inv_d;
+            if (inv_d < 0.0) std::swap(t0, t1);
+            t_in = f_max(t_in, t0);
+            t_out = f_min(t_out, t1);
+            if (t_out <= t_in) return false;
+        }
+        return true;
+    }
+};
+static inline AABB surrounding_box(const AABB& b0, const AABB& b1) {  // aabb.rs:40-51
+    Vec3 mn(f_min(b0.min.x(), b1.min.x()), f_min(b0.min.y(), b1.min.y()), f_min(b0.min.z(), b1.min.z()));
+    Vec3 mx(f_max(b0.max.x(), b1.max.x()), f_max(b0.max.y(), b1.max.y()), f_max(b0.max.z(), b1.max.z()));
+    return AABB(mn, mx);
+}
+
+// ---------------------------------------------------------------- src/texture.rs, src/perlin.rs
+struct Texture {
+    virtual ~Texture() {}
+    virtual Color mapping(double u, double v, const Vec3& p, Sampler& s) const = 0;   // texture.rs:5-7
+};
+struct ConstantTexture : Texture {
+    Color value;
+    explicit ConstantTexture(const Color& c) : value(c) {}
+    Color mapping(double, double, const Vec3&, Sampler&) const override { return value; }   // texture.rs:23-27
+};
+struct CheckTexture : Texture {
+    const Texture* odd; const Texture* even;
+    CheckTexture(const Texture* o, const Texture* e) : odd(o), even(e) {}
+    Color mapping(double u, double v, const Vec3& p, Sampler& s) const override {          // texture.rs:45-54
+        double sines = std::sin(10.0 * p.x()) * std::sin(10.0 * p.y()) * std::sin(10.0 * p.z());
+        if (sines < 0.0) return odd->mapping(u, v, p, s);
+        return even->mapping(u, v, p, s);
+    }
+};
+// perlin.rs:39-56
+static double perlin_interp(const Vec3 c[2][2][2], double u, double v, double w) {
+    double uu = u * u * (3.0 - 2.0 * u);
+    double vv = v * v * (3.0 - 2.0 * v);
+    double ww = w * w * (3.0 - 2.0 * w);
+    double accum = 0.0;
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int k = 0; k < 2; k++) {
+                Vec3 weight(u - (double)i, v - (double)j, w - (double)k);
+                accum += ((double)i * uu + (double)(1 - i) * (1.0 - uu)) *
+                         ((double)j * vv + (double)(1 - j) * (1.0 - vv)) *
+                         ((double)k * ww + (double)(1 - k) * (1.0 - ww)) *
+                         c[i][j][k].dot(weight);
+            }
+    return accum;
+}
+struct Perlin {
+    std::vector<Vec3> rd_vec;
+    std::vector<size_t> perm_x, perm_y, perm_z;
+    // perlin.rs:13-19 generate_vector, :21-28 permute, :30-37 generate_perm, :67-75 new
+    static std::vector<size_t> generate_perm(Sampler& s) {
+        std::vector<size_t> p(256);
+        for (size_t i = 0; i < 256; i++) p[i] = i;
+        for (int i = 255; i >= 0; i--) {
+            uint32_t target = s.rng.index((uint32_t)i + 1);       // gen_range(0..=i)
+            std::swap(p[(size_t)i], p[target]);
+        }
+        return p;
+    }
+    explicit Perlin(Sampler& s) {
+        rd_vec.reserve(256);
+        for (int i = 0; i < 256; i++) rd_vec.push_back(random_in_unit_sphere(s));
+        perm_x = generate_perm(s);
+        perm_y = generate_perm(s);
+        perm_z = generate_perm(s);
+    }
+    double perlin(const Point3& p, double scale) const {            // perlin.rs:77-109
+        double u = scale * p.x() - std::floor(scale * p.x());
+        double v = scale * p.y() - std::floor(scale * p.y());
+        double w = scale * p.z() - std::floor(scale * p.z());
+        u = u * u * (3.0 - 2.0 * u);
+        v = v * v * (3.0 - 2.0 * v);
+        w = w * w * (3.0 - 2.0 * w);
+        size_t i = (size_t)as_u64(std::floor(scale * p.x()));      // `as usize` saturates negatives to 0
+        size_t j = (size_t)as_u64(std::floor(scale * p.y()));
+        size_t k = (size_t)as_u64(std::floor(scale * p.z()));
+        Vec3 c[2][2][2];
+        for (size_t di = 0; di < 2; di++)
+            for (size_t dj = 0; dj < 2; dj++)
+                for (size_t dk = 0; dk < 2; dk++)
+                    c[di][dj][dk] = rd_vec[perm_x[(i + di) & 255] ^ perm_y[(j + dj) & 255] ^ perm_z[(k + dk) & 255]];
+        return perlin_interp(c, u, v, w);
+    }
+    double turb(const Vec3& p, double scale, size_t depth) const {  // perlin.rs:111-120
+        double accum = 0.0;
+        Vec3 temp_p = p;
+        double weight = 1.0;
+        for (size_t i = 0; i < depth; i++) {
+            accum += weight * perlin(temp_p, scale);
+            weight *= 0.5;
+            temp_p = temp_p * 2.0;
+        }
+        return std::fabs(accum);
+    }
+};
+struct NoiseTexture : Texture {
+    Perlin noise; double scale;
+    NoiseTexture(double sc, Sampler& s) : noise(s), scale(sc) {}     // texture.rs:63-68
+    Color mapping(double, double, const Vec3& p, Sampler& s) const override {   // texture.rs:71-79
+        s.c.perlin_evals += 7;
+        return Color(1.0, 1.0, 1.0) * 0.5 * (1.0 + std::sin(scale * p.z() + 10.0 * noise.turb(p, scale, 7)));
+    }
+};
+struct ImageTexture : Texture {
+    std::vector<uint8_t> data; uint32_t width, height;
+    ImageTexture(const uint8_t* d, uint32_t w, uint32_t h) : data(d, d + (size_t)3 * w * h), width(w), height(h) {}
+    Color mapping(double u, double v, const Vec3&, Sampler& s) const override {  // texture.rs:99-120
+        size_t w = width, h = height;
+        size_t i = (size_t)as_u64(f_clamp(u, 0.0, 1.0) * (double)w);
+        size_t j = (size_t)as_u64(f_clamp(1.0 - v, 0.0, 1.0) * (double)h);
+        if (i > w - 1) i = w - 1;
+        if (j > h - 1) j = h - 1;
+        size_t idx = 3 * i + 3 * w * j;
+        s.c.texels++;
+        return Color((double)data[idx] / 255.0, (double)data[idx + 1] / 255.0, (double)data[idx + 2] / 255.0);
+    }
+};
+
+// ---------------------------------------------------------------- src/hit.rs
+struct Material;
+struct HitRecord {                                                     // hit.rs:9-24
+    Point3 position; Vec3 normal; double t = 0, u = 0, v = 0; bool front_face = false;
+    const Material* material = nullptr;
+    void set_face_normal(const Ray& r, const Vec3& outward_normal) {  // hit.rs:34-41
+        front_face = r.direction().dot(outward_normal) < 0.0;
+        normal = front_face ? outward_normal : (-1.0) * outward_normal;
+    }
+};
+struct Hittable {                                                      // hit.rs:26-31
+    virtual ~Hittable() {}
+    virtual bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const = 0;
+    virtual bool bounding_box(double t0, double t1, AABB& out) const = 0;
+    virtual double pdf_value(const Point3&, const Vec3&, Sampler&) const { return 0.0; }
+    virtual Vec3 random(const Vec3&, Sampler&) const { return Vec3(1.0, 0.0, 0.0); }
+};
+struct HittableList : Hittable {                                       // hit.rs:46-97
+    std::vector<const Hittable*> list;
+    void push(const Hittable* h) { list.push_back(h); }
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
+        bool any = false;
+        double closest_so_far = t_max;
+        HitRecord tmp;
+        for (const Hittable* object : list) {
+            if (object->hit(r, t_min, closest_so_far, s, tmp)) {
+                closest_so_far = tmp.t;
+                rec = tmp;
+                any = true;
+            }
+        }
+        return any;
+    }
+    bool bounding_box(double t0, double t1, AABB& out) const override {
+        if (list.empty()) return false;
+        AABB acc;
+        if (!list[0]->bounding_box(t0, t1, acc)) return false;
+        for (size_t i = 1; i < list.size(); i++) {
+            AABB b;
+            if (!list[i]->bounding_box(t0, t1, b)) return false;
+            acc = surrounding_box(acc, b);
+        }
+        out = acc;
+        return true;
+    }
+    double pdf_value(const Point3& o, const Vec3& v, Sampler& s) const override {   // hit.rs:90-92
+        double sum = 0.0;
+        for (const Hittable* h : list) sum += h->pdf_value(o, v, s);
+        return sum / (double)list.size();
+    }
+    Vec3 random(const Vec3& o, Sampler& s) const override {                          // hit.rs:94-96
+        uint32_t i = s.rng.index((uint32_t)list.size());
+        return list[i]->random(o, s);
+    }
+};
+struct FlipNormal : Hittable {                                         // hit.rs:99-132
+    const Hittable* hittable;
+    explicit FlipNormal(const Hittable* h) : hittable(h) {}
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
+        if (!hittable->hit(r, t_min, t_max, s, rec)) return false;
+        rec.front_face = !rec.front_face;
+        return true;
+    }
+    bool bounding_box(double t0, double t1, AABB& out) const override { return hittable->bounding_box(t0, t1, out); }
+    double pdf_value(const Point3& o, const Vec3& v, Sampler& s) const override { return hittable->pdf_value(o, v, s); }
+    Vec3 random(const Vec3& o, Sampler& s) const override { return hittable->random(o, s); }
+};
+
+// ---------------------------------------------------------------- src/pdf.rs (Cosine / Hittable / Mixture)
+static Vec3 random_cosine_direction(Sampler& s) {                      // pdf.rs:8-18
+    double r1 = s.rng.u01();
+    double r2 = s.rng.u01();
+    double z = std::sqrt(1.0 - r2);
+    double phi = 2.0 * PI * r1;
+    double x = std::cos(phi) * std::sqrt(r2);
+    double y = std::sin(phi) * std::sqrt(r2);
+    return Vec3(x, y, z);
+}
+struct PDF {                                                           // pdf.rs:62-67
+    enum Kind { Cosine, HittableK, Mixture } kind;
+    ONB uvw;                                  // Cosine
+    Point3 origin; const Hittable* hittable;  // Hittable
+    const PDF* p0; const PDF* p1;             // Mixture
+    static PDF cosine_pdf(const Vec3& w) { PDF p; p.kind = Cosine; p.uvw = ONB::build_from_w(w); p.hittable = nullptr; p.p0 = p.p1 = nullptr; return p; }   // pdf.rs:81-85
+    static PDF hittable_pdf(const Point3& o, const Hittable* h) { PDF p; p.kind = HittableK; p.origin = o; p.hittable = h; p.p0 = p.p1 = nullptr; return p; }   // pdf.rs:87-89
+    static PDF mixture_pdf(const PDF* a, const PDF* b) { PDF p; p.kind = Mixture; p.hittable = nullptr; p.p0 = a; p.p1 = b; return p; }                        // pdf.rs:91-93
+    double value(const Vec3& r_out, Sampler& s) const {                // pdf.rs:95-147
+        switch (kind) {
+        case Cosine: {
+            double cosine = r_out.normalized().dot(uvw.w());
+            return (cosine > 0.0) ? cosine / PI : 0.0;
+        }
+        case HittableK: return hittable->pdf_value(origin, r_out, s);
+        default: return 0.5 * p0->value(r_out, s) + 0.5 * p1->value(r_out, s);
+        }
+    }
+    Vec3 generate(Sampler& s) const {                                  // pdf.rs:149-176
+        switch (kind) {
+        case Cosine: return uvw.local(random_cosine_direction(s));
+        case HittableK: return hittable->random(origin, s);
+        default: return s.rng.boolean() ? p0->generate(s) : p1->generate(s);
+        }
+    }
+};
+
+// ---------------------------------------------------------------- src/mat.rs (Lambertian, Metal, Dielectric, DiffuseLight, Isotropic)
+struct ScatterRecord {                                                 // mat.rs:79-83 (Microfacet arm: PBR, out of scope)
+    enum Kind { Specular, Scatter } kind;
+    Ray specular_ray; Color attenuation; PDF pdf;
+};
+struct Material {                                                      // mat.rs:54-77
+    virtual ~Material() {}
+    virtual bool scatter_mc_method(const Ray&, const HitRecord&, Sampler&, ScatterRecord&) const { return false; }
+    virtual double scattering_pdf(const Ray&, const HitRecord&, const Ray&) const { return 0.0; }
+    virtual Color emitted(const HitRecord&, Sampler&) const { return Color(0.0, 0.0, 0.0); }
+};
+struct Lambertian : Material {                                         // mat.rs:200-250
+    const Texture* albedo;
+    explicit Lambertian(const Texture* t) : albedo(t) {}
+    bool scatter_mc_method(const Ray&, const HitRecord& rec, Sampler& s, ScatterRecord& out) const override {
+        out.kind = ScatterRecord::Scatter;
+        out.pdf = PDF::cosine_pdf(rec.normal);
+        out.attenuation = albedo->mapping(rec.u, rec.v, rec.position, s);
+        return true;
+    }
+    double scattering_pdf(const Ray&, const HitRecord& rec, const Ray& scattered) const override {
+        double cosine = f_max(rec.normal.dot(scattered.direction().normalized()), 0.0);
+        return cosine / PI;
+    }
+};
+struct Metal : Material {                                              // mat.rs:253-294
+    Color albedo; double fuzz;
+    Metal(const Color& a, double f) : albedo(a), fuzz(f) {}
+    bool scatter_mc_method(const Ray& r_in, const HitRecord& rec, Sampler& s, ScatterRecord& out) const override {
+        Vec3 reflected = r_in.direction().reflect(rec.normal).normalized();
+        Ray scattered(rec.position, reflected + fuzz * random_in_unit_sphere(s), r_in.time());
+        if (scattered.direction().dot(rec.normal) > 0.0) {
+            out.kind = ScatterRecord::Specular;
+            out.specular_ray = scattered;
+            out.attenuation = albedo;
+            return true;
+        }
+        return false;
+    }
+};
+struct Dielectric : Material {                                         // mat.rs:297-375
+    double ir;
+    explicit Dielectric(double i) : ir(i) {}
+    static double reflectance(double cosine, double index_of_refraction) {   // mat.rs:309-313
+        double q = (1.0 - index_of_refraction) / (1.0 + index_of_refraction);
+        double r0 = q * q;
+        double m = 1.0 - cosine;
+        double m2 = m * m;                      // powi(5) = m * ((m*m)*(m*m)) (square-and-multiply)
+        return r0 + (1.0 - r0) * (m * (m2 * m2));
+    }
+    bool scatter_mc_method(const Ray& r_in, const HitRecord& rec, Sampler& s, ScatterRecord& out) const override {   // mat.rs:343-374
+        Color attenuation(1.0, 1.0, 1.0);
+        double refraction_ratio = rec.front_face ? 1.0 / ir : ir;
+        Vec3 unit_direction = r_in.direction().normalized();
+        double cos_theta = f_min(((-1.0) * unit_direction).dot(rec.normal), 1.0);
+        double sin_theta = std::sqrt(1.0 - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > 1.0;
+        bool will_reflect = s.rng.u01() < reflectance(cos_theta, refraction_ratio);
+        Vec3 direction = (cannot_refract || will_reflect) ? unit_direction.reflect(rec.normal)
+                                                          : unit_direction.refract(rec.normal, refraction_ratio);
+        out.kind = ScatterRecord::Specular;
+        out.specular_ray = Ray(rec.position, direction, r_in.time());
+        out.attenuation = attenuation;
+        return true;
+    }
+};
+struct DiffuseLight : Material {                                       // mat.rs:377-402
+    const Texture* emit;
+    explicit DiffuseLight(const Texture* t) : emit(t) {}
+    Color emitted(const HitRecord& rec, Sampler& s) const override {
+        if (rec.front_face) return emit->mapping(rec.u, rec.v, rec.position, s);
+        return Color(0.0, 0.0, 0.0);
+    }
+};
+struct Isotropic : Material {                                          // mat.rs:404-422: only the old `scatter` is implemented,
+    const Texture* albedo;                                             // so on the scatter_mc_method path it absorbs
+    explicit Isotropic(const Texture* t) : albedo(t) {}
+};
+
+// ---------------------------------------------------------------- src/sphere.rs
+static void get_sphere_uv(const Vec3& p, double& u, double& v) {       // sphere.rs:11-25
+    double phi = std::atan2(-p.z(), p.x()) + PI;
+    double theta = std::acos(-p.y());
+    u = phi / (2.0 * PI);
+    v = theta / PI;
+}
+static Vec3 random_to_sphere(double radius, double distance_squared, Sampler& s) {   // sphere.rs:27-36
+    double r1 = s.rng.u01();
+    double r2 = s.rng.u01();
+    double z = 1.0 + r2 * (std::sqrt(1.0 - radius * radius / distance_squared) - 1.0);
+    double phi = 2.0 * PI * r1;
+    double x = std::cos(phi) * std::sqrt(1.0 - z * z);
+    double y = std::sin(phi) * std::sqrt(1.0 - z * z);
+    return Vec3(x, y, z);
+}
+static inline double sq_of_len(const Vec3& v) { double l = v.length(); return l * l; }   // `.length().powi(2)`
+// shared body of Sphere::hit / MovingSphere::hit (sphere.rs:56-95, :150-189)
+static bool sphere_hit_body(const Point3& center, double radius, const Material* material, const Ray& r, double t_min, double t_max, HitRecord& rec) {
+    Vec3 oc = r.origin() - center;
+    double a = sq_of_len(r.direction());
+    double half_b = oc.dot(r.direction());
+    double c = sq_of_len(oc) - radius * radius;
+    double discriminant = half_b * half_b - a * c;
+    if (discriminant < 0.0) return false;
+    double sqrt_d = std::sqrt(discriminant);
+    double root = (-half_b - sqrt_d) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrt_d) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    rec.position = r.at(root);
+    rec.normal = Vec3(0.0, 0.0, 0.0);
+    rec.t = root; rec.u = 0.0; rec.v = 0.0; rec.front_face = false; rec.material = material;
+    Vec3 outward_normal = (rec.position - center) / radius;
+    rec.set_face_normal(r, outward_normal);
+    get_sphere_uv(outward_normal, rec.u, rec.v);
+    return true;
+}
+struct Sphere : Hittable {
+    Point3 center; double radius; const Material* material;
+    Sphere(const Point3& c, double r, const Material* m) : center(c), radius(r), material(m) {}
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
+        s.c.sphere_tests++;
+        return sphere_hit_body(center, radius, material, r, t_min, t_max, rec);
+    }
+    bool bounding_box(double, double, AABB& out) const override {      // sphere.rs:97-102
+        out = AABB(center - Vec3(radius, radius, radius), center + Vec3(radius, radius, radius));
+        return true;
+    }
+    double pdf_value(const Point3& o, const Vec3& v, Sampler& s) const override {   // sphere.rs:104-112
+        s.c.light_pdf++;
+        HitRecord rec;
+        if (sphere_hit_body(center, radius, material, Ray(o, v, 0.0), 0.001, F64_MAX, rec)) {
+            double cos_theta_max = std::sqrt(1.0 - radius * radius / sq_of_len(center - o));
+            double solid_angle = 2.0 * PI * (1.0 - cos_theta_max);
+            return 1.0 / solid_angle;
+        }
+        return 0.0;
+    }
+    Vec3 random(const Vec3& o, Sampler& s) const override {            // sphere.rs:114-119
+        s.c.light_random++;
+        Vec3 direction = center - o;
+        double distance_squared = sq_of_len(direction);
+        ONB uvw = ONB::build_from_w(direction);
+        return uvw.local(random_to_sphere(radius, distance_squared, s));
+    }
+};
+struct MovingSphere : Hittable {
+    Point3 center0, center1; double time0, time1, radius; const Material* material;
+    MovingSphere(const Point3& c0, const Point3& c1, double t0, double t1, double r, const Material* m)
+        : center0(c0), center1(c1), time0(t0), time1(t1), radius(r), material(m) {}
+    Point3 center(double time) const {                                 // sphere.rs:144-146
+        return center0 + (time - time0) / (time1 - time0) * (center1 - center0);
+    }
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
+        s.c.msphere_tests++;
+        return sphere_hit_body(center(r.time()), radius, material, r, t_min, t_max, rec);
+    }
+    bool bounding_box(double, double, AABB& out) const override {      // sphere.rs:191-201
+        Vec3 rr(radius, radius, radius);
+        out = surrounding_box(AABB(center0 - rr, center0 + rr), AABB(center1 - rr, center1 + rr));
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- src/rect.rs
+enum Plane { PLANE_XY = 0, PLANE_XZ = 1, PLANE_YZ = 2 };
+static inline void plane_axes(int plane, int& k, int& a, int& b) {     // rect.rs:26-32
+    switch (plane) {
+    case PLANE_YZ: k = 0; a = 1; b = 2; break;
+    case PLANE_XZ: k = 1; a = 0; b = 2; break;
+    default:       k = 2; a = 0; b = 1; break;
+    }
+}
+struct AARect : Hittable {
+    int plane; double a0, a1, b0, b1, k; const Material* material;
+    AARect(int p, double a0_, double a1_, double b0_, double b1_, double k_, const Material* m)
+        : plane(p), a0(a0_), a1(a1_), b0(b0_), b1(b1_), k(k_), material(m) {}
+    bool hit_body(const Ray& r, double t_min, double t_max, HitRecord& rec) const {   // rect.rs:49-81
+        int ki, ai, bi;
+        plane_axes(plane, ki, ai, bi);
+        double t = (k - r.origin()[ki]) / r.direction()[ki];
+        if (t < t_min || t > t_max) return false;
+        double a = r.origin()[ai] + t * r.direction()[ai];
+        double b = r.origin()[bi] + t * r.direction()[bi];
+        if (a < a0 || a > a1 || b < b0 || b > b1) return false;
+        rec.u = (a - a0) / (a1 - a0);
+        rec.v = (b - b0) / (b1 - b0);
+        rec.position = r.at(t);
+        Vec3 normal(0.0, 0.0, 0.0);
+        normal[ki] = 1.0;
+        rec.normal = normal; rec.t = t; rec.front_face = false; rec.material = material;
+        rec.set_face_normal(r, normal);
+        return true;
+    }
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
+        s.c.rect_tests++;
+        return hit_body(r, t_min, t_max, rec);
+    }
+    bool bounding_box(double, double, AABB& out) const override {      // rect.rs:83-89 (ignores `plane`, reference quirk B4)
+        out = AABB(Vec3(a0, b0, k - 0.0001), Vec3(a1, b1, k + 0.0001));
+        return true;
+    }
+    double pdf_value(const Point3& o, const Vec3& v, Sampler& s) const override {    // rect.rs:91-101
+        s.c.light_pdf++;
+        HitRecord rec;
+        if (hit_body(Ray(o, v, 0.0), 0.001, F64_INF, rec)) {
+            double area = (a1 - a0) * (b1 - b0);
+            double distance_squared = (rec.t * rec.t) * sq_of_len(v);
+            double cosine = std::fabs(v.dot(rec.normal)) / v.length();
+            return (cosine != 0.0) ? distance_squared / (cosine * area) : 0.0;
+        }
+        return 0.0;
+    }
+    Vec3 random(const Vec3& o, Sampler& s) const override {            // rect.rs:103-111
+        s.c.light_random++;
+        int ki, ai, bi;
+        plane_axes(plane, ki, ai, bi);
+        Vec3 random_point(0.0, 0.0, 0.0);
+        random_point[ai] = s.rng.range(a0, a1);
+        random_point[bi] = s.rng.range(b0, b1);
+        random_point[ki] = k;
+        return random_point - o;
+    }
+};
+
+// ---------------------------------------------------------------- src/cube.rs
+struct Cube : Hittable {
+    Point3 min, max; HittableList sides; std::vector<std::unique_ptr<AARect>> owned;
+    Cube(const Point3& mn, const Point3& mx, const Material* m) : min(mn), max(mx) {   // cube.rs:14-31
+        auto add = [&](int plane, double a0, double a1, double b0, double b1, double k) {
+            owned.emplace_back(new AARect(plane, a0, a1, b0, b1, k, m));
+            sides.push(owned.back().get());
+        };
+        add(PLANE_XY, mn.x(), mx.x(), mn.y(), mx.y(), mx.z());
+        add(PLANE_XY, mn.x(), mx.x(), mn.y(), mx.y(), mn.z());
+        add(PLANE_XZ, mn.x(), mx.x(), mn.z(), mx.z(), mx.y());
+        add(PLANE_XZ, mn.x(), mx.x(), mn.z(), mx.z(), mn.y());
+        add(PLANE_YZ, mn.y(), mx.y(), mn.z(), mx.z(), mx.x());
+        add(PLANE_YZ, mn.y(), mx.y(), mn.z(), mx.z(), mn.x());
+    }
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override { return sides.hit(r, t_min, t_max, s, rec); }   // cube.rs:35-37
+    bool bounding_box(double, double, AABB& out) const override { out = AABB(min, max); return true; }                                                // cube.rs:39-46
+};
+
+// ---------------------------------------------------------------- src/tri.rs
+struct Triangle : Hittable {
+    Point3 vertices[3]; const Material* material;
+    Triangle(const Point3& a, const Point3& b, const Point3& c, const Material* m) : vertices{a, b, c}, material(m) {}
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& sm, HitRecord& rec) const override {   // tri.rs:24-57
+        sm.c.tri_tests++;
+        Vec3 s = r.origin() - vertices[0];
+        Vec3 e1 = vertices[1] - vertices[0];
+        Vec3 e2 = vertices[2] - vertices[0];
+        Vec3 s1 = r.direction().cross(e2);
+        Vec3 s2 = s.cross(e1);
+        double s1_e1 = s1.dot(e1);
+        double t = s2.dot(e2) / s1_e1;
+        double b1 = s1.dot(s) / s1_e1;
+        double b2 = s2.dot(r.direction()) / s1_e1;
+        if (t < t_min || t > t_max) return false;
+        if (b1 < 0.0 || b2 < 0.0 || (1.0 - b1 - b2) < 0.0) return false;
+        rec.position = r.at(t);
+        Vec3 normal = e1.cross(e2).normalized();
+        rec.normal = normal; rec.t = t; rec.u = b1; rec.v = b2; rec.front_face = false; rec.material = material;
+        rec.set_face_normal(r, normal);
+        return true;
+    }
+    bool bounding_box(double, double, AABB& out) const override {      // tri.rs:59-70
+        Vec3 mn, mx;
+        for (int a = 0; a < 3; a++) {
+            mn[a] = f_min(vertices[0][a], f_min(vertices[1][a], vertices[2][a]));
+            mx[a] = f_max(vertices[0][a], f_max(vertices[1][a], vertices[2][a]));
+        }
+        out = AABB(mn, mx);
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------- src/translate.rs, src/rotate.rs
+struct Translate : Hittable {
+    const Hittable* hittable; Vec3 offset;
+    Translate(const Hittable* h, const Vec3& o) : hittable(h), offset(o) {}
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // translate.rs:22-30
+        s.c.xforms++;
+        Ray translated_ray(r.origin() - offset, r.direction(), r.time());
+        if (!hittable->hit(translated_ray, t_min, t_max, s, rec)) return false;
+        rec.position = rec.position + offset;
+        return true;
+    }
+    bool bounding_box(double t0, double t1, AABB& out) const override {                                // translate.rs:32-40
+        if (!hittable->bounding_box(t0, t1, out)) return false;
+        out.min = out.min + offset; out.max = out.max + offset;
+        return true;
+    }
+};
+enum Axis { AXIS_X = 0, AXIS_Y = 1, AXIS_Z = 2 };
+static inline void axis_index(int axis, int& r, int& a, int& b) {      // rotate.rs:14-20
+    switch (axis) {
+    case AXIS_X: r = 0; a = 1; b = 2; break;
+    case AXIS_Y: r = 1; a = 0; b = 2; break;
+    default:     r = 2; a = 0; b = 1; break;
+    }
+}
+struct Rotate : Hittable {
+    int axis; double sin_theta, cos_theta; const Hittable* hittable; bool has_box; AABB aabb;
+    Rotate(int ax, const Hittable* h, double angle) : axis(ax), hittable(h) {                         // rotate.rs:32-74
+        double radiants = (PI / 180.0) * angle;
+        sin_theta = std::sin(radiants);
+        cos_theta = std::cos(radiants);
+        AABB b;
+        has_box = h->bounding_box(0.0, 1.0, b);
+        if (has_box) {
+            // rotate.rs:40-57: min starts at f64::MIN (= -MAX) with `<` updates and max at f64::MAX with `>`
+            // updates, so neither ever changes (reference quirk B3): the box is all of space.
+            Vec3 mn(-F64_MAX, -F64_MAX, -F64_MAX), mx(F64_MAX, F64_MAX, F64_MAX);
+            int r_axis, a_axis, b_axis;
+            axis_index(axis, r_axis, a_axis, b_axis);
+            for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+                double r = (double)k * b.max[r_axis] + (double)(1 - k) * b.min[r_axis];
+                double a = (double)i * b.max[a_axis] + (double)(1 - i) * b.min[a_axis];
+                double bb = (double)j * b.max[b_axis] + (double)(1 - j) * b.min[b_axis];
+                double new_a = cos_theta * a + sin_theta * bb;
+                double new_b = -sin_theta * a + cos_theta * bb;
+                if (new_a < mn[a_axis]) mn[a_axis] = new_a;
+                if (new_b < mn[b_axis]) mn[b_axis] = new_b;
+                if (r < mn[r_axis]) mn[r_axis] = r;
+                if (new_a > mx[a_axis]) mx[a_axis] = new_a;
+                if (new_b > mx[b_axis]) mx[b_axis] = new_b;
+                if (r > mx[r_axis]) mx[r_axis] = r;
+            }
+            aabb = AABB(mn, mx);
+        }
+    }
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // rotate.rs:77-106
+        s.c.xforms++;
+        int r_axis, a_axis, b_axis;
+        axis_index(axis, r_axis, a_axis, b_axis);
+        Vec3 origin = r.origin();
+        Vec3 direction = r.direction();
+        origin[a_axis] = cos_theta * r.origin()[a_axis] - sin_theta * r.origin()[b_axis];
+        origin[b_axis] = sin_theta * r.origin()[a_axis] + cos_theta * r.origin()[b_axis];
+        direction[a_axis] = cos_theta * r.direction()[a_axis] - sin_theta * r.direction()[b_axis];
+        direction[b_axis] = sin_theta * r.direction()[a_axis] + cos_theta * r.direction()[b_axis];
+        Ray rotated_ray(origin, direction, r.time());
+        if (!hittable->hit(rotated_ray, t_min, t_max, s, rec)) return false;
+        Vec3 position = rec.position;
+        Vec3 normal = rec.normal;
+        position[a_axis] = cos_theta * rec.position[a_axis] + sin_theta * rec.position[b_axis];
+        position[b_axis] = (-sin_theta) * rec.position[a_axis] + cos_theta * rec.position[b_axis];
+        normal[a_axis] = cos_theta * rec.normal[a_axis] + sin_theta * rec.normal[b_axis];
+        normal[b_axis] = (-sin_theta) * rec.normal[a_axis] + cos_theta * rec.normal[b_axis];
+        rec.position = position;
+        rec.set_face_normal(rotated_ray, normal);     // quirk B2: object-space ray vs world-space normal
+        return true;
+    }
+    bool bounding_box(double, double, AABB& out) const override { if (has_box) out = aabb; return has_box; }   // rotate.rs:108-110
+};
+
+// ---------------------------------------------------------------- src/medium.rs
+struct ConstantMedium : Hittable {
+    const Hittable* boundary; double density; Isotropic phase_function;
+    ConstantMedium(const Hittable* b, double d, const Texture* t) : boundary(b), density(d), phase_function(t) {}
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // medium.rs:27-61
+        s.c.medium_tests++;
+        HitRecord hit1, hit2;
+        if (boundary->hit(r, -F64_MAX, F64_MAX, s, hit1)) {
+            if (boundary->hit(r, hit1.t + 0.0001, F64_MAX, s, hit2)) {
+                if (hit1.t < t_min) hit1.t = t_min;
+                if (hit2.t > t_max) hit2.t = t_max;
+                if (hit1.t < hit2.t) {
+                    double distance_inside_boundary = (hit2.t - hit1.t) * r.direction().length();
+                    double hit_distance = (-(1.0 / density)) * std::log(s.rng.u01());
+                    if (hit_distance < distance_inside_boundary) {
+                        double t = hit1.t + hit_distance / r.direction().length();
+                        rec.position = r.at(t);
+                        rec.u = 0.0; rec.v = 0.0; rec.t = t;
+                        rec.front_face = false;
+                        rec.normal = Vec3(1.0, 0.0, 0.0);
+                        rec.material = &phase_function;
+                        return true;
+                    }
+                }
+            }
+        }
+        return false;
+    }
+    bool bounding_box(double t0, double t1, AABB& out) const override { return boundary->bounding_box(t0, t1, out); }
+};
+
+// ---------------------------------------------------------------- src/bvh.rs
+struct BVH : Hittable {
+    std::unique_ptr<BVH> left, right; const Hittable* leaf = nullptr; AABB bbox;
+    // bvh.rs:18-73.  `sort_unstable_by` leaves the order of equal keys unspecified; this restatement
+    // uses a stable sort (ties keep insertion order).  Tie order changes traversal cost only, never results.
+    BVH(std::vector<const Hittable*> hit, double time0, double time1) {
+        if (hit.empty()) { fprintf(stderr, "oracle: no object in the scene\n"); abort(); }     // bvh.rs:55
+        auto box_of = [&](const Hittable* h) { AABB b; if (!h->bounding_box(time0, time1, b)) { fprintf(stderr, "oracle: no bounding box in bvh node\n"); abort(); } return b; };
+        double best_range = 0; int axis = 0;
+        for (int a = 0; a < 3; a++) {                                                         // bvh.rs:33-48
+            double mn = F64_MAX, mx = -F64_MAX;
+            for (const Hittable* h : hit) { AABB b = box_of(h); mn = f_min(mn, b.min[a]); mx = f_max(mx, b.max[a]); }
+            double range = mx - mn;
+            if (a == 0 || range > best_range) { best_range = range; axis = a; }               // descending sort, first of equals wins
+        }
+        std::stable_sort(hit.begin(), hit.end(), [&](const Hittable* x, const Hittable* y) {  // bvh.rs:19-31,51
+            AABB a = box_of(x), b = box_of(y);
+            return (a.min[axis] + a.max[axis]) < (b.min[axis] + b.max[axis]);
+        });
+        size_t length = hit.size();
+        if (length == 1) {
+            leaf = hit[0];
+            bbox = box_of(leaf);
+        } else {
+            std::vector<const Hittable*> upper(hit.begin() + length / 2, hit.end());          // bvh.rs:65 drain(length/2..) -> right
+            hit.resize(length / 2);
+            right.reset(new BVH(upper, time0, time1));
+            left.reset(new BVH(hit, time0, time1));
+            bbox = surrounding_box(left->bbox, right->bbox);
+        }
+    }
+    bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // bvh.rs:77-91
+        s.c.bvh_nodes++;
+        if (!bbox.hit(r, t_min, t_max)) return false;
+        if (leaf) return leaf->hit(r, t_min, t_max, s, rec);
+        HitRecord l;
+        bool hl = left->hit(r, t_min, t_max, s, l);
+        if (hl) t_max = l.t;
+        HitRecord rr;
+        bool hr = right->hit(r, t_min, t_max, s, rr);
+        if (hr) { rec = rr; return true; }
+        if (hl) { rec = l; return true; }
+        return false;
+    }
+    bool bounding_box(double, double, AABB& out) const override { out = bbox; return true; }          // bvh.rs:93-95
+};
+
+// ---------------------------------------------------------------- src/camera.rs
+struct Camera {
+    Point3 origin, lower_left_corner; Vec3 horizontal, vertical, cu, cv; double lens_radius, time0, time1;
+    Camera() : lens_radius(0), time0(0), time1(0) {}
+    Camera(const Point3& lookfrom, const Point3& lookat, const Vec3& vup, double vfov, double aspect_ratio,
+           double aperture, double focus_dist, double t0, double t1) {                               // camera.rs:19-49
+        double theta = PI / 180.0 * vfov;
+        double viewport_height = 2.0 * std::tan(theta / 2.0);
+        double viewport_width = viewport_height * aspect_ratio;
+        Vec3 cw = (lookfrom - lookat).normalized();
+        cu = vup.cross(cw).normalized();
+        cv = cw.cross(cu);
+        Vec3 h = focus_dist * viewport_width * cu;
+        Vec3 v = focus_dist * viewport_height * cv;
+        Vec3 llc = lookfrom - h / 2.0 - v / 2.0 - focus_dist * cw;
+        origin = lookfrom; horizontal = h; vertical = v; lower_left_corner = llc;
+        lens_radius = aperture / 2.0; time0 = t0; time1 = t1;
+    }
+    Ray get_ray(double s, double t, Sampler& smp) const {                                            // camera.rs:51-59
+        Vec3 rd = lens_radius * random_in_unit_disk(smp);
+        Vec3 offset = cu * rd.x() + cv * rd.y();
+        double time = time0 + smp.rng.u01() * (time1 - time0);
+        return Ray(origin + offset, lower_left_corner + s * horizontal + t * vertical - (origin + offset), time);
+    }
+};
+
+// ---------------------------------------------------------------- src/main.rs:41-120  ray_color
+static Color ray_color(const Ray& ray, const Color& background, const Hittable* world, const HittableList* lights, uint64_t depth, Sampler& s) {
+    if (depth <= 0) return Color(0.0, 0.0, 0.0);                                                     // main.rs:42-45
+    s.c.world_hits++;
+    HitRecord rec;
+    if (world->hit(ray, 0.00001, F64_INF, s, rec)) {                                                 // main.rs:48
+        s.c.shades++;
+        Color emitted = rec.material->emitted(rec, s);                                               // main.rs:62
+        ScatterRecord srec;
+        if (rec.material->scatter_mc_method(ray, rec, s, srec)) {                                    // main.rs:86
+            s.c.bounces++;
+            if (srec.kind == ScatterRecord::Specular) {                                              // main.rs:89-91
+                return srec.attenuation * ray_color(srec.specular_ray, background, world, lights, depth - 1, s);
+            }
+            // ScatterRecord::Scatter, main.rs:92-98
+            Vec3 dir; double pdf_value;
+            if (lights->list.empty()) {                                                              // deviation D2
+                dir = srec.pdf.generate(s);
+                pdf_value = srec.pdf.value(dir, s);
+            } else {
+                PDF hittable_pdf = PDF::hittable_pdf(rec.position, lights);
+                PDF mixture_pdf = PDF::mixture_pdf(&hittable_pdf, &srec.pdf);
+                dir = mixture_pdf.generate(s);
+                pdf_value = mixture_pdf.value(dir, s);
+            }
+            Ray scattered(rec.position, dir, ray.time());
+            return emitted + srec.attenuation * rec.material->scattering_pdf(ray, rec, scattered) *
+                                 ray_color(scattered, background, world, lights, depth - 1, s) / pdf_value;
+        }
+        return emitted;                                                                              // main.rs:108-110
+    }
+    return background;                                                                               // main.rs:118
+}
+
+// ---------------------------------------------------------------- scene container (host side of the test C API)
+struct Scene {
+    std::vector<std::unique_ptr<Texture>> textures;
+    std::vector<std::unique_ptr<Material>> materials;
+    std::vector<std::unique_ptr<Hittable>> hittables;
+    const Hittable* world = nullptr;
+    HittableList lights;            // always a list, as in every scene fn of main.rs
+    std::string error;
+    int add(Hittable* h) { hittables.emplace_back(h); return (int)hittables.size() - 1; }
+    int add(Material* m) { materials.emplace_back(m); return (int)materials.size() - 1; }
+    int add(Texture* t) { textures.emplace_back(t); return (int)textures.size() - 1; }
+};
+
+// one sample of the per-pixel closure, main.rs:811-830
+static inline Color sample_pixel(const Scene& sc, const Camera& cam, const Color& bg, uint32_t W, uint32_t H,
+                                 uint32_t i, uint32_t j, uint32_t s_idx, uint64_t depth, uint64_t seed, Counters& cnt) {
+    Sampler smp;
+    uint32_t pixel = (H - 1 - j) * W + i;          // output order: row 0 is j = H-1 (main.rs:772)
+    smp.rng = Rng::for_path(seed, pixel, s_idx);
+    double random_u = smp.rng.u01();
+    double random_v = smp.rng.u01();
+    double u = ((double)i + random_u) / (double)(W - 1);
+    double v = ((double)j + random_v) / (double)(H - 1);
+    Ray r = cam.get_ray(u, v, smp);
+    Color c = ray_color(r, bg, sc.world, &sc.lights, depth, smp);
+    smp.c.samples++;
+    if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]))) smp.c.nonfinite++;
+    cnt.add(smp.c);
+    return c;
+}
+
+} // namespace orc
+
+// ==================================================================== C API (ctypes; mirrors include/rt_amd.h names with orc_ prefix)
+using namespace orc;
+extern "C" {
+
+struct orc_camera { double lookfrom[3], lookat[3], vup[3], vfov, aspect, aperture, focus_dist, time0, time1; };
+
+void* orc_scene_create() { return new Scene(); }
+void orc_scene_destroy(void* s) { delete (Scene*)s; }
+#define SC ((Scene*)s)
+static Vec3 V(const double* p) { return Vec3(p[0], p[1], p[2]); }
+
+void* orc_rng_create(uint64_t seed, uint32_t stream) { Sampler* r = new Sampler(); r->rng = Rng::for_stream(seed, stream); return r; }
+void orc_rng_destroy(void* r) { delete (Sampler*)r; }
+double orc_rng_f64(void* r) { return ((Sampler*)r)->rng.u01(); }
+double orc_rng_range(void* r, double a, double b) { return ((Sampler*)r)->rng.range(a, b); }
+int orc_rng_bool(void* r) { return ((Sampler*)r)->rng.boolean() ? 1 : 0; }
+uint32_t orc_rng_index(void* r, uint32_t n) { return ((Sampler*)r)->rng.index(n); }
+uint32_t orc_rng_u32(void* r) { return ((Sampler*)r)->rng.next_u32(); }
+void orc_rng_path(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t out[4]) { Rng g = Rng::for_path(seed, pixel, sample); for (int i = 0; i < 4; i++) out[i] = g.s[i]; }
+
+int orc_texture_constant(void* s, const double* rgb) { return SC->add(new ConstantTexture(V(rgb))); }
+int orc_texture_check(void* s, int odd, int even) { return SC->add(new CheckTexture(SC->textures[odd].get(), SC->textures[even].get())); }
+int orc_texture_noise(void* s, double scale, void* rng) { return SC->add(new NoiseTexture(scale, *(Sampler*)rng)); }
+int orc_texture_image(void* s, const uint8_t* rgb8, uint32_t w, uint32_t h) { return SC->add(new ImageTexture(rgb8, w, h)); }
+
+int orc_material_lambertian(void* s, int tex) { return SC->add(new Lambertian(SC->textures[tex].get())); }
+int orc_material_metal(void* s, const double* albedo, double fuzz) { return SC->add(new Metal(V(albedo), fuzz)); }
+int orc_material_dielectric(void* s, double ir) { return SC->add(new Dielectric(ir)); }
+int orc_material_diffuse_light(void* s, int tex) { return SC->add(new DiffuseLight(SC->textures[tex].get())); }
+int orc_material_isotropic(void* s, int tex) { return SC->add(new Isotropic(SC->textures[tex].get())); }
+
+#define MAT(m) (SC->materials[m].get())
+#define HIT(h) (SC->hittables[h].get())
+int orc_sphere(void* s, const double* c, double r, int mat) { return SC->add(new Sphere(V(c), r, MAT(mat))); }
+int orc_moving_sphere(void* s, const double* c0, const double* c1, double t0, double t1, double r, int mat) { return SC->add(new MovingSphere(V(c0), V(c1), t0, t1, r, MAT(mat))); }
+int orc_aarect(void* s, int plane, double a0, double a1, double b0, double b1, double k, int mat) { return SC->add(new AARect(plane, a0, a1, b0, b1, k, MAT(mat))); }
+int orc_cube(void* s, const double* mn, const double* mx, int mat) { return SC->add(new Cube(V(mn), V(mx), MAT(mat))); }
+int orc_triangle(void* s, const double* v9, int mat) { return SC->add(new Triangle(V(v9), V(v9 + 3), V(v9 + 6), MAT(mat))); }
+int orc_list_create(void* s) { return SC->add(new HittableList()); }
+int orc_list_push(void* s, int list, int h) { ((HittableList*)HIT(list))->push(HIT(h)); return 0; }
+// Mesh::new, mesh.rs:16-31: returns the HittableList `tris`
+int orc_mesh(void* s, const double* positions, uint32_t npos, const uint32_t* indices, uint32_t nidx, int mat) {
+    HittableList* tris = new HittableList();
+    int id = SC->add(tris);
+    for (uint32_t i = 0; i < nidx / 3; i++) {
+        uint32_t a = indices[i * 3], b = indices[i * 3 + 1], c = indices[i * 3 + 2];
+        if (a >= npos || b >= npos || c >= npos) { SC->error = "mesh index out of range"; return -1; }
+        Triangle* t = new Triangle(V(positions + 3 * a), V(positions + 3 * b), V(positions + 3 * c), MAT(mat));
+        SC->add(t);
+        tris->push(t);
+    }
+    return id;
+}
+int orc_flip_normal(void* s, int h) { return SC->add(new FlipNormal(HIT(h))); }
+int orc_translate(void* s, int h, const double* offset) { return SC->add(new Translate(HIT(h), V(offset))); }
+int orc_rotate(void* s, int axis, int h, double angle) { return SC->add(new Rotate(axis, HIT(h), angle)); }
+int orc_constant_medium(void* s, int boundary, double density, int tex) { return SC->add(new ConstantMedium(HIT(boundary), density, SC->textures[tex].get())); }
+int orc_bvh(void* s, const int* ids, uint32_t n, double t0, double t1) {
+    if (n == 0) { SC->error = "no object in the scene"; return -1; }
+    std::vector<const Hittable*> v;
+    for (uint32_t i = 0; i < n; i++) v.push_back(HIT(ids[i]));
+    return SC->add(new BVH(v, t0, t1));
+}
+int orc_bvh_of_list(void* s, int list, double t0, double t1) {
+    HittableList* l = (HittableList*)HIT(list);
+    if (l->list.empty()) { SC->error = "no object in the scene"; return -1; }
+    return SC->add(new BVH(l->list, t0, t1));
+}
+int orc_scene_set_world(void* s, int h) { SC->world = HIT(h); return 0; }
+int orc_lights_push(void* s, int h) { SC->lights.push(HIT(h)); return 0; }
+const char* orc_scene_error(void* s) { return SC->error.c_str(); }
+
+static Camera make_camera(const orc_camera* c) {
+    return Camera(V(c->lookfrom), V(c->lookat), V(c->vup), c->vfov, c->aspect, c->aperture, c->focus_dist, c->time0, c->time1);
+}
+// Camera::new fields, for host-logic tests: origin, llc, horizontal, vertical, cu, cv (18) + lens_radius, time0, time1
+void orc_camera_fields(const orc_camera* c, double* out21) {
+    Camera cam = make_camera(c);
+    const Vec3* vs[6] = {&cam.origin, &cam.lower_left_corner, &cam.horizontal, &cam.vertical, &cam.cu, &cam.cv};
+    for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) out21[i * 3 + k] = (*vs[i])[k];
+    out21[18] = cam.lens_radius; out21[19] = cam.time0; out21[20] = cam.time1;
+}
+
+// Render rows [row0, row1) of the output image (row 0 = top = j = H-1).  out_sum: W*H*3 doubles (full image
+// layout; only the requested rows are written).  out_samples (optional): W*H*spp*3 per-sample radiance.
+// counters (optional): Counters::N uint64.  nthreads <= 0: hardware concurrency.
+// mode 0: parallel over rows (dynamic); mode 1: "reference-shaped" = pixels sequential, samples of one pixel
+// split across threads (main.rs:811), summed in sample order afterwards.
+int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, uint32_t H, uint32_t spp, uint64_t depth,
+               uint64_t seed, uint32_t row0, uint32_t row1, int nthreads, int mode, double* out_sum, double* out_samples, uint64_t* counters) {
+    if (!SC->world) { SC->error = "world not set"; return -1; }
+    if (W < 2 || H < 2) { SC->error = "W and H must be >= 2 (u,v divide by W-1, H-1)"; return -1; }
+    Camera cam = make_camera(camp);
+    Color background = V(bg);
+    if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+    if (nthreads <= 0) nthreads = 1;
+    if (row1 > H) row1 = H;
+    std::vector<Counters> cnts((size_t)nthreads);
+    const Scene& sc = *SC;
+    if (mode == 0) {
+        std::atomic<uint32_t> next(row0);
+        auto work = [&](int tid) {
+            for (;;) {
+                uint32_t row = next.fetch_add(1);
+                if (row >= row1) break;
+                uint32_t j = H - 1 - row;
+                for (uint32_t i = 0; i < W; i++) {
+                    Color pixel(0.0, 0.0, 0.0);
+                    size_t p = (size_t)row * W + i;
+                    for (uint32_t k = 0; k < spp; k++) {
+                        Color c = sample_pixel(sc, cam, background, W, H, i, j, k, depth, seed, cnts[(size_t)tid]);
+                        pixel = pixel + c;
+                        if (out_samples) for (int ch = 0; ch < 3; ch++) out_samples[(p * spp + k) * 3 + (size_t)ch] = c[ch];
+                    }
+                    for (int ch = 0; ch < 3; ch++) out_sum[p * 3 + (size_t)ch] = pixel[ch];
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto& t : th) t.join();
+    } else {
+        std::vector<Color> buf(spp);
+        for (uint32_t row = row0; row < row1; row++) {
+            uint32_t j = H - 1 - row;
+            for (uint32_t i = 0; i < W; i++) {
+                std::atomic<uint32_t> next(0);
+                auto work = [&](int tid) {
+                    for (;;) {
+                        uint32_t k0 = next.fetch_add(16);
+                        if (k0 >= spp) break;
+                        for (uint32_t k = k0; k < std::min(spp, k0 + 16); k++)
+                            buf[k] = sample_pixel(sc, cam, background, W, H, i, j, k, depth, seed, cnts[(size_t)tid]);
+                    }
+                };
+                std::vector<std::thread> th;
+                for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+                work(0);
+                for (auto& t : th) t.join();
+                Color pixel(0.0, 0.0, 0.0);
+                size_t p = (size_t)row * W + i;
+                for (uint32_t k = 0; k < spp; k++) {
+                    pixel = pixel + buf[k];
+                    if (out_samples) for (int ch = 0; ch < 3; ch++) out_samples[(p * spp + k) * 3 + (size_t)ch] = buf[k][ch];
+                }
+                for (int ch = 0; ch < 3; ch++) out_sum[p * 3 + (size_t)ch] = pixel[ch];
+            }
+        }
+    }
+    if (counters) {
+        Counters tot;
+        for (auto& c : cnts) tot.add(c);
+        std::memcpy(counters, &tot.samples, sizeof(uint64_t) * Counters::N);
+    }
+    return 0;
+}
+int orc_counters_n() { return Counters::N; }
+int orc_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
+
+// Vec3::format_color (vec.rs:125-131) on a per-pixel sum
+void orc_format_color(const double* rgb_sum, uint64_t spp, uint64_t* out3) { format_color(V(rgb_sum), spp, out3); }
+
+// ---- function-level entry points for known-answer tests
+void orc_sphere_uv(const double* p, double* uv) { get_sphere_uv(V(p), uv[0], uv[1]); }
+void orc_reflect(const double* v, const double* n, double* out) { Vec3 r = V(v).reflect(V(n)); for (int i = 0; i < 3; i++) out[i] = r[i]; }
+void orc_refract(const double* v, const double* n, double eta, double* out) { Vec3 r = V(v).refract(V(n), eta); for (int i = 0; i < 3; i++) out[i] = r[i]; }
+double orc_reflectance(double cosine, double ir) { return Dielectric::reflectance(cosine, ir); }
+void orc_onb(const double* n, double* out9) { ONB o = ONB::build_from_w(V(n)); for (int a = 0; a < 3; a++) for (int i = 0; i < 3; i++) out9[a * 3 + i] = o.axis[a][i]; }
+int orc_aabb_hit(const double* mn, const double* mx, const double* o, const double* d, double t_in, double t_out) { return AABB(V(mn), V(mx)).hit(Ray(V(o), V(d), 0.0), t_in, t_out) ? 1 : 0; }
+// generic hit on any hittable handle: out = position(3) normal(3) t u v front_face(0/1)
+int orc_hit(void* s, int h, const double* o, const double* d, double time, double t_min, double t_max, void* rng, double* out10) {
+    Sampler tmp; tmp.rng = Rng::for_stream(0, 0);
+    Sampler& smp = rng ? *(Sampler*)rng : tmp;
+    HitRecord rec;
+    if (!HIT(h)->hit(Ray(V(o), V(d), time), t_min, t_max, smp, rec)) return 0;
+    for (int i = 0; i < 3; i++) { out10[i] = rec.position[i]; out10[3 + i] = rec.normal[i]; }
+    out10[6] = rec.t; out10[7] = rec.u; out10[8] = rec.v; out10[9] = rec.front_face ? 1.0 : 0.0;
+    return 1;
+}
+double orc_pdf_value(void* s, int h, const double* o, const double* v) { Sampler tmp; tmp.rng = Rng::for_stream(0, 0); return HIT(h)->pdf_value(V(o), V(v), tmp); }
+void orc_random(void* s, int h, const double* o, void* rng, double* out3) { Vec3 r = HIT(h)->random(V(o), *(Sampler*)rng); for (int i = 0; i < 3; i++) out3[i] = r[i]; }
+double orc_lights_pdf_value(void* s, const double* o, const double* v) { Sampler tmp; tmp.rng = Rng::for_stream(0, 0); return SC->lights.pdf_value(V(o), V(v), tmp); }
+void orc_cosine_generate(const double* n, void* rng, double* out3) { PDF p = PDF::cosine_pdf(V(n)); Vec3 r = p.generate(*(Sampler*)rng); for (int i = 0; i < 3; i++) out3[i] = r[i]; }
+double orc_cosine_value(const double* n, const double* dir) { Sampler tmp; PDF p = PDF::cosine_pdf(V(n)); return p.value(V(dir), tmp); }
+void orc_texture_value(void* s, int tex, double u, double v, const double* p, double* out3) { Sampler tmp; Color c = SC->textures[tex]->mapping(u, v, V(p), tmp); for (int i = 0; i < 3; i++) out3[i] = c[i]; }
+int orc_bounding_box(void* s, int h, double t0, double t1, double* out6) { AABB b; if (!HIT(h)->bounding_box(t0, t1, b)) return 0; for (int i = 0; i < 3; i++) { out6[i] = b.min[i]; out6[3 + i] = b.max[i]; } return 1; }
+// one camera ray: consumes the same draws as main.rs:813-820; out = origin(3) dir(3) time
+void orc_camera_ray(const orc_camera* c, uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint64_t seed, uint32_t s_idx, double* out7) {
+    Camera cam = make_camera(c);
+    Sampler smp; smp.rng = Rng::for_path(seed, (H - 1 - j) * W + i, s_idx);
+    double ru = smp.rng.u01(), rv = smp.rng.u01();
+    Ray r = cam.get_ray(((double)i + ru) / (double)(W - 1), ((double)j + rv) / (double)(H - 1), smp);
+    for (int k = 0; k < 3; k++) { out7[k] = r.orig[k]; out7[3 + k] = r.dir[k]; }
+    out7[6] = r.tm;
+}
+// ray_color on an explicit ray with an explicit stream (furnace / estimator tests)
+void orc_ray_color(void* s, const double* o, const double* d, double time, const double* bg, uint64_t depth, void* rng, double* out3) {
+    Color c = ray_color(Ray(V(o), V(d), time), V(bg), SC->world, &SC->lights, depth, *(Sampler*)rng);
+    for (int i = 0; i < 3; i++) out3[i] = c[i];
+}
+
+} // extern "C"

@@ -1,0 +1,54 @@
+"""Loader for the product library `csrc/librt_amd.so` (C-ABI of include/rt_amd.h).
+
+Fails loudly when the library has not been built: there is no fallback renderer of any kind.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .api import Backend, CameraParams, c_double_p, c_u32_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+
+_backend = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load() -> Backend:
+    """Load librt_amd.so once and declare the render entry points."""
+    global _backend
+    if _backend is not None:
+        return _backend
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} is missing: build it with `make -C raytracinginrust_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    be = Backend(lib, "rt_")
+    cam_p = C.POINTER(CameraParams)
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_device_count.restype = C.c_int
+    lib.rt_scene_flatten.restype = C.c_int
+    lib.rt_scene_flatten.argtypes = [C.c_void_p, c_u32_p]
+    lib.rt_local_tiles.restype = C.c_uint32
+    lib.rt_local_tiles.argtypes = [C.c_uint32] * 5
+    common = [C.c_void_p, cam_p, c_double_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+    lib.rt_render.restype = C.c_int
+    lib.rt_render.argtypes = common + [C.c_void_p]
+    lib.rt_render_samples.restype = C.c_int
+    lib.rt_render_samples.argtypes = common + [C.c_void_p, C.c_void_p]
+    lib.rt_render_device.restype = C.c_int
+    lib.rt_render_device.argtypes = common + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.rt_last_kernel_ms.restype = C.c_int
+    lib.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.rt_last_stats.restype = C.c_int
+    lib.rt_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.rt_write_ppm.restype = C.c_int
+    lib.rt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
+    _backend = be
+    return be

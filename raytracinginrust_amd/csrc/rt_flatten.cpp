@@ -1,0 +1,326 @@
+// csrc/rt_flatten.cpp — host side: turn the builder tree (one node per reference constructor) into the
+// flat device scene of rt_ir.h; BVH build (src/bvh.rs:18-73), Camera::new (src/camera.rs:19-49).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include "rt_scene.h"
+
+namespace rt {
+
+namespace {
+
+const double F64_MAX = std::numeric_limits<double>::max();
+
+struct Box { double mn[3], mx[3]; };
+
+struct Flattener {
+    Scene& s;
+    HostFlat& f;
+    std::map<int, uint32_t> prim_of_node;   // node id -> first primitive index in its pool (emitted once, shared)
+    std::string err;
+    explicit Flattener(Scene& sc) : s(sc), f(sc.flat) {}
+
+    bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
+
+    // ---- primitive pools
+    uint32_t rect_of(int n) {
+        auto it = prim_of_node.find(n);
+        if (it != prim_of_node.end()) return it->second;
+        const HNode& h = s.nodes[n];
+        DRect<double> r{h.v[0], h.v[1], h.v[2], h.v[3], h.v[4], (uint32_t)h.plane_or_axis, (uint32_t)h.mat};
+        f.rects.push_back(r);
+        return prim_of_node[n] = (uint32_t)f.rects.size() - 1;
+    }
+    uint32_t cube_of(int n) {   // Cube::new, src/cube.rs:14-31: six AARects in this order
+        auto it = prim_of_node.find(n);
+        if (it != prim_of_node.end()) return it->second;
+        const HNode& h = s.nodes[n];
+        const double* mn = h.v; const double* mx = h.v + 3;
+        uint32_t first = (uint32_t)f.rects.size();
+        uint32_t m = (uint32_t)h.mat;
+        f.rects.push_back({mn[0], mx[0], mn[1], mx[1], mx[2], 0u /*XY*/, m});
+        f.rects.push_back({mn[0], mx[0], mn[1], mx[1], mn[2], 0u, m});
+        f.rects.push_back({mn[0], mx[0], mn[2], mx[2], mx[1], 1u /*XZ*/, m});
+        f.rects.push_back({mn[0], mx[0], mn[2], mx[2], mn[1], 1u, m});
+        f.rects.push_back({mn[1], mx[1], mn[2], mx[2], mx[0], 2u /*YZ*/, m});
+        f.rects.push_back({mn[1], mx[1], mn[2], mx[2], mn[0], 2u, m});
+        return prim_of_node[n] = first;
+    }
+    uint32_t sphere_of(int n) {
+        auto it = prim_of_node.find(n);
+        if (it != prim_of_node.end()) return it->second;
+        const HNode& h = s.nodes[n];
+        f.spheres.push_back({{h.v[0], h.v[1], h.v[2]}, h.v[3], (uint32_t)h.mat, 0u});
+        f.feats |= F_SPHERES;
+        return prim_of_node[n] = (uint32_t)f.spheres.size() - 1;
+    }
+    uint32_t msphere_of(int n) {
+        auto it = prim_of_node.find(n);
+        if (it != prim_of_node.end()) return it->second;
+        const HNode& h = s.nodes[n];
+        f.mspheres.push_back({{h.v[0], h.v[1], h.v[2]}, {h.v[3], h.v[4], h.v[5]}, h.v[6], h.v[7], h.v[8], (uint32_t)h.mat, 0u});
+        f.feats |= F_SPHERES;
+        return prim_of_node[n] = (uint32_t)f.mspheres.size() - 1;
+    }
+    uint32_t tri_of(int n) {
+        auto it = prim_of_node.find(n);
+        if (it != prim_of_node.end()) return it->second;
+        const HNode& h = s.nodes[n];
+        DTri<double> t;
+        for (int k = 0; k < 3; k++) {
+            t.v0[k] = h.v[k];
+            t.e1[k] = h.v[3 + k] - h.v[k];     // tri.rs:27
+            t.e2[k] = h.v[6 + k] - h.v[k];     // tri.rs:28
+        }
+        t.mat = (uint32_t)h.mat; t.pad = 0;
+        f.tris.push_back(t);
+        f.feats |= F_TRIS;
+        return prim_of_node[n] = (uint32_t)f.tris.size() - 1;
+    }
+
+    static bool is_bare_prim(HNode::Kind k) { return k == HNode::SPHERE || k == HNode::MSPHERE || k == HNode::RECT || k == HNode::TRI; }
+
+    // geometry of a bare primitive / cube node as (kind, first, count)
+    bool simple_geom(int n, uint32_t& kind, uint32_t& first, uint32_t& count) {
+        const HNode& h = s.nodes[n];
+        switch (h.kind) {
+        case HNode::RECT: kind = G_RECT; first = rect_of(n); count = 1; return true;
+        case HNode::CUBE: kind = G_RECT; first = cube_of(n); count = 6; return true;
+        case HNode::SPHERE: kind = G_SPHERE; first = sphere_of(n); count = 1; return true;
+        case HNode::MSPHERE: kind = G_MSPHERE; first = msphere_of(n); count = 1; return true;
+        case HNode::TRI: kind = G_TRI; first = tri_of(n); count = 1; return true;
+        default: return false;
+        }
+    }
+
+    // ---- bounding boxes (only what BVH::new needs: src/sphere.rs:97-102,191-201, src/rect.rs:83-89,
+    //      src/cube.rs:39-46, src/tri.rs:59-70)
+    bool bbox(int n, Box& b) {
+        const HNode& h = s.nodes[n];
+        switch (h.kind) {
+        case HNode::SPHERE:
+            for (int k = 0; k < 3; k++) { b.mn[k] = h.v[k] - h.v[3]; b.mx[k] = h.v[k] + h.v[3]; }
+            return true;
+        case HNode::MSPHERE:
+            for (int k = 0; k < 3; k++) {
+                double r = h.v[8];
+                b.mn[k] = std::fmin(h.v[k] - r, h.v[3 + k] - r);
+                b.mx[k] = std::fmax(h.v[k] + r, h.v[3 + k] + r);
+            }
+            return true;
+        case HNode::RECT:     // ignores `plane` (reference quirk)
+            b.mn[0] = h.v[0]; b.mn[1] = h.v[2]; b.mn[2] = h.v[4] - 0.0001;
+            b.mx[0] = h.v[1]; b.mx[1] = h.v[3]; b.mx[2] = h.v[4] + 0.0001;
+            return true;
+        case HNode::CUBE:
+            for (int k = 0; k < 3; k++) { b.mn[k] = h.v[k]; b.mx[k] = h.v[3 + k]; }
+            return true;
+        case HNode::TRI:
+            for (int k = 0; k < 3; k++) {
+                b.mn[k] = std::fmin(h.v[k], std::fmin(h.v[3 + k], h.v[6 + k]));
+                b.mx[k] = std::fmax(h.v[k], std::fmax(h.v[3 + k], h.v[6 + k]));
+            }
+            return true;
+        default:
+            return false;
+        }
+    }
+
+    // ---- BVH::new, src/bvh.rs:18-73.  Emits nodes in DFS preorder (left child = parent + 1).
+    // `sort_unstable_by` leaves ties unspecified; a stable sort is used (tie order changes cost, never results).
+    bool build_bvh(std::vector<int> items, uint32_t depth, uint32_t& out_index, Box& out_box) {
+        if (items.empty()) return fail("no object in the scene");                    // bvh.rs:55
+        if (depth > (uint32_t)RT_MAX_BVH_DEPTH) return fail("BVH deeper than RT_MAX_BVH_DEPTH");
+        f.bvh_depth = std::max(f.bvh_depth, depth);
+        std::vector<Box> boxes(items.size());
+        for (size_t i = 0; i < items.size(); i++)
+            if (!bbox(items[i], boxes[i])) return fail("unsupported BVH child (only Sphere, MovingSphere, AARect, Cube, Triangle have device leaf forms)");
+        int axis = 0; double best = 0;
+        for (int a = 0; a < 3; a++) {                                                 // bvh.rs:33-48
+            double mn = F64_MAX, mx = -F64_MAX;
+            for (const Box& b : boxes) { mn = std::fmin(mn, b.mn[a]); mx = std::fmax(mx, b.mx[a]); }
+            double range = mx - mn;
+            if (a == 0 || range > best) { best = range; axis = a; }
+        }
+        std::vector<size_t> order(items.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {       // bvh.rs:19-31,51
+            return (boxes[x].mn[axis] + boxes[x].mx[axis]) < (boxes[y].mn[axis] + boxes[y].mx[axis]);
+        });
+        uint32_t me = (uint32_t)f.bvh.size();
+        out_index = me;
+        f.bvh.push_back(DBvhNode<double>{});
+        size_t length = items.size();
+        if (length == 1) {
+            uint32_t kind, first, count;
+            if (!simple_geom(items[0], kind, first, count)) return fail("unsupported BVH child");
+            if (first >= (1u << 28)) return fail("too many primitives");
+            out_box = boxes[0];
+            DBvhNode<double>& nd = f.bvh[me];
+            for (int k = 0; k < 3; k++) { nd.mn[k] = out_box.mn[k]; nd.mx[k] = out_box.mx[k]; }
+            nd.a = BVH_LEAF | (kind << 28) | first;
+            nd.b = count;
+            return true;
+        }
+        std::vector<int> lower, upper;
+        for (size_t i = 0; i < length / 2; i++) lower.push_back(items[order[i]]);
+        for (size_t i = length / 2; i < length; i++) upper.push_back(items[order[i]]);   // bvh.rs:65: drain(length/2..) -> right
+        uint32_t li, ri; Box lb, rb;
+        if (!build_bvh(lower, depth + 1, li, lb)) return false;
+        if (!build_bvh(upper, depth + 1, ri, rb)) return false;
+        for (int k = 0; k < 3; k++) { out_box.mn[k] = std::fmin(lb.mn[k], rb.mn[k]); out_box.mx[k] = std::fmax(lb.mx[k], rb.mx[k]); }   // aabb.rs:40-51
+        DBvhNode<double>& nd = f.bvh[me];
+        for (int k = 0; k < 3; k++) { nd.mn[k] = out_box.mn[k]; nd.mx[k] = out_box.mx[k]; }
+        nd.a = li;      // == me + 1
+        nd.b = ri;
+        return true;
+    }
+
+    // ---- world flattening
+    struct Chain { DOp<double> ops[RT_MAX_OPS]; int n = 0; };
+
+    bool emit_object(uint32_t kind, uint32_t first, uint32_t count, const Chain& chain, int medium) {
+        DObject o{};
+        o.geom_kind = kind; o.geom_first = first; o.geom_count = count;
+        o.first_op = (uint32_t)f.ops.size(); o.n_ops = (uint32_t)chain.n; o.medium = medium;
+        for (int i = 0; i < chain.n; i++) f.ops.push_back(chain.ops[i]);
+        f.objects.push_back(o);
+        return true;
+    }
+
+    bool emit(int n, const Chain& chain, int medium) {
+        if (n < 0 || n >= (int)s.nodes.size()) return fail("bad hittable handle");
+        const HNode& h = s.nodes[n];
+        uint32_t kind, first, count;
+        switch (h.kind) {
+        case HNode::SPHERE: case HNode::MSPHERE: case HNode::RECT: case HNode::TRI: case HNode::CUBE:
+            simple_geom(n, kind, first, count);
+            return emit_object(kind, first, count, chain, medium);
+        case HNode::LIST: {
+            // HittableList::hit (hit.rs:59-71) keeps the closest hit, later items winning ties, and wrappers
+            // act per hit, so Wrapper(List[a,b]) == List[Wrapper(a), Wrapper(b)].  A ConstantMedium boundary
+            // is different (two boundary queries, medium.rs:29-30) and must stay one object.
+            if (medium >= 0 && h.items.size() != 1) {
+                // a homogeneous run of bare prims can still be one typed range
+            }
+            size_t i = 0;
+            bool emitted_any = false;
+            while (i < h.items.size()) {
+                const HNode& c = s.nodes[h.items[i]];
+                // run of consecutive bare primitives of one kind whose records are contiguous -> one range object
+                if (is_bare_prim(c.kind) && prim_of_node.find(h.items[i]) == prim_of_node.end()) {
+                    size_t j = i;
+                    while (j < h.items.size() && s.nodes[h.items[j]].kind == c.kind && prim_of_node.find(h.items[j]) == prim_of_node.end()) j++;
+                    uint32_t k0 = 0, f0 = 0, c0 = 0;
+                    for (size_t t = i; t < j; t++) { uint32_t kk, ff, cc; simple_geom(h.items[t], kk, ff, cc); if (t == i) { k0 = kk; f0 = ff; } c0++; }
+                    if (medium >= 0 && (emitted_any || j < h.items.size())) return fail("ConstantMedium boundary must flatten to one object");
+                    if (!emit_object(k0, f0, c0, chain, medium)) return false;
+                    emitted_any = true;
+                    i = j;
+                } else {
+                    if (medium >= 0 && (emitted_any || h.items.size() != 1)) return fail("ConstantMedium boundary must flatten to one object");
+                    if (!emit(h.items[i], chain, medium)) return false;
+                    emitted_any = true;
+                    i++;
+                }
+            }
+            if (medium >= 0 && !emitted_any) return fail("ConstantMedium boundary is an empty list");
+            return true;
+        }
+        case HNode::FLIP: case HNode::TRANSLATE: case HNode::ROTATE: {
+            if (chain.n >= RT_MAX_OPS) return fail("wrapper chain longer than RT_MAX_OPS");
+            Chain c2 = chain;
+            DOp<double>& op = c2.ops[c2.n++];
+            op = DOp<double>{};
+            if (h.kind == HNode::FLIP) op.kind = OP_FLIP;
+            else if (h.kind == HNode::TRANSLATE) { op.kind = OP_TRANSLATE; op.x = h.v[0]; op.y = h.v[1]; op.z = h.v[2]; }
+            else {
+                op.kind = OP_ROTATE; op.axis = (uint32_t)h.plane_or_axis;
+                double radiants = (3.14159265358979323846264338327950288 / 180.0) * h.v[0];    // rotate.rs:34-36
+                op.x = std::sin(radiants); op.y = std::cos(radiants);
+            }
+            return emit(h.child, c2, medium);
+        }
+        case HNode::MEDIUM: {
+            if (medium >= 0) return fail("nested ConstantMedium is not supported");
+            if (chain.n != 0) return fail("ConstantMedium inside Translate/Rotate/FlipNormal is not supported (make it the outermost wrapper)");
+            // Isotropic::new(texture), medium.rs:21
+            DMaterial<double> iso{}; iso.kind = M_ISOTROPIC; iso.tex = (uint32_t)h.mat;
+            f.materials.push_back(iso);
+            DMedium<double> m{}; m.neg_inv_density = -(1.0 / h.v[0]); m.mat = (uint32_t)f.materials.size() - 1;
+            f.media.push_back(m);
+            f.feats |= F_MEDIUM;
+            return emit(h.child, chain, (int)f.media.size() - 1);
+        }
+        case HNode::BVH: {
+            uint32_t root; Box b;
+            if (!build_bvh(h.items, 1, root, b)) return false;
+            f.feats |= F_BVH;
+            return emit_object(G_BVH, root, 1, chain, medium);
+        }
+        }
+        return fail("unknown node kind");
+    }
+
+    bool run() {
+        f = HostFlat{};
+        f.materials = s.materials;
+        f.textures = s.textures;
+        for (const auto& m : f.materials) if (m.kind == M_DIELECTRIC) f.feats |= F_DIELECTRIC;
+        for (const auto& t : f.textures) if (t.kind != T_CONSTANT) f.feats |= F_TEXTURES;
+        if (s.world < 0) return fail("world not set");
+        Chain c;
+        if (!emit(s.world, c, -1)) return false;
+        // lights: HittableList of FlipNormal(AARect) / AARect / Sphere (hit.rs:90-96, 125-132; rect.rs:91-111; sphere.rs:104-119);
+        // anything else has the trait defaults pdf_value = 0, random = (1,0,0) (hit.rs:29-30)
+        for (int l : s.lights) {
+            int n = l;
+            while (s.nodes[n].kind == HNode::FLIP) n = s.nodes[n].child;
+            const HNode& h = s.nodes[n];
+            if (h.kind == HNode::RECT) f.lights.push_back({L_RECT, rect_of(n)});
+            else if (h.kind == HNode::SPHERE) f.lights.push_back({L_SPHERE, sphere_of(n)});
+            else if (h.kind == HNode::LIST) return fail("a HittableList nested inside `lights` is not supported");
+            else f.lights.push_back({L_OTHER, 0});
+        }
+        return true;
+    }
+};
+
+} // namespace
+
+bool flatten_scene(Scene& s) {
+    if (s.flat_valid) return true;
+    Flattener fl(s);
+    if (!fl.run()) { s.error = fl.err; return false; }
+    s.flat_valid = true;
+    return true;
+}
+
+// Camera::new, src/camera.rs:19-49
+void camera_new(const rt_camera_args& a, DCamera<double>& out) {
+    const double PI = 3.14159265358979323846264338327950288;
+    auto sub = [](const double* x, const double* y, double* r) { for (int k = 0; k < 3; k++) r[k] = x[k] - y[k]; };
+    auto cross = [](const double* x, const double* y, double* r) {
+        r[0] = x[1] * y[2] - x[2] * y[1]; r[1] = x[2] * y[0] - x[0] * y[2]; r[2] = x[0] * y[1] - x[1] * y[0];
+    };
+    auto normalize = [](double* x) { double l = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]); for (int k = 0; k < 3; k++) x[k] = x[k] / l; };
+    double theta = PI / 180.0 * a.vfov;
+    double viewport_height = 2.0 * std::tan(theta / 2.0);
+    double viewport_width = viewport_height * a.aspect;
+    double cw[3], cu[3], cv[3];
+    sub(a.lookfrom, a.lookat, cw); normalize(cw);
+    cross(a.vup, cw, cu); normalize(cu);
+    cross(cw, cu, cv);
+    for (int k = 0; k < 3; k++) {
+        double h = a.focus_dist * viewport_width * cu[k];     // (focus_dist * viewport_width) * cu
+        double v = a.focus_dist * viewport_height * cv[k];
+        out.horizontal[k] = h; out.vertical[k] = v;
+        out.lower_left_corner[k] = a.lookfrom[k] - h / 2.0 - v / 2.0 - a.focus_dist * cw[k];
+        out.origin[k] = a.lookfrom[k]; out.cu[k] = cu[k]; out.cv[k] = cv[k];
+    }
+    out.lens_radius = a.aperture / 2.0; out.time0 = a.time0; out.time1 = a.time1;
+}
+
+} // namespace rt

@@ -1,0 +1,447 @@
+// csrc/rt_host.cpp — C-ABI of librt_amd.so (include/rt_amd.h): scene builder handles, device upload,
+// kernel launch, format_color / PPM emitter.  There is NO CPU rendering path in this library: without a
+// HIP device rt_render* fail with an error.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/rt_amd.h"
+#include "rt_scene.h"
+#include "rt_launch.h"
+
+using namespace rt;
+
+struct rt_scene { Scene s; };
+struct rt_rng { Rng r; };
+
+static thread_local std::string g_err;
+static int set_err(const std::string& m) { g_err = m; return -1; }
+static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_err = m; return -1; }
+
+#define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_err = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
+
+static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+template <typename T> static void free_device_scene(DeviceScene<T>& d) {
+    free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
+    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image);
+    d.valid = false;
+}
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_err.c_str(); }
+int rt_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+// ---------------------------------------------------------------- rng
+rt_rng* rt_rng_create(uint64_t seed, uint32_t stream) { rt_rng* r = new rt_rng(); r->r = rng_for_stream(seed, stream); return r; }
+void rt_rng_destroy(rt_rng* r) { delete r; }
+double rt_rng_f64(rt_rng* r) { return rng_u01(r->r, 0.0); }
+double rt_rng_range(rt_rng* r, double a, double b) { return rng_range(r->r, a, b); }
+int rt_rng_bool(rt_rng* r) { return rng_bool(r->r) ? 1 : 0; }
+uint32_t rt_rng_index(rt_rng* r, uint32_t n) { return rng_index(r->r, n); }
+uint32_t rt_rng_u32(rt_rng* r) { return rng_u32(r->r); }
+void rt_rng_path(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t out[4]) {
+    Rng g = rng_for_path(seed, pixel, sample);
+    out[0] = g.s0; out[1] = g.s1; out[2] = g.s2; out[3] = g.s3;
+}
+
+// ---------------------------------------------------------------- scene
+rt_scene* rt_scene_create(void) { return new rt_scene(); }
+
+void rt_scene_destroy(rt_scene* sc) {
+    if (!sc) return;
+    free_device_scene(sc->s.dev64);
+    free_device_scene(sc->s.dev32);
+    free_dev(sc->s.d_queue); free_dev(sc->s.d_stats);
+    if (sc->s.ev_start) (void)hipEventDestroy((hipEvent_t)sc->s.ev_start);
+    if (sc->s.ev_stop) (void)hipEventDestroy((hipEvent_t)sc->s.ev_stop);
+    delete sc;
+}
+const char* rt_scene_error(rt_scene* sc) { return sc->s.error.c_str(); }
+
+static void touch(rt_scene* sc) {
+    sc->s.invalidate();
+    free_device_scene(sc->s.dev64);
+    free_device_scene(sc->s.dev32);
+}
+static bool tex_ok(rt_scene* sc, int t) { return t >= 0 && t < (int)sc->s.textures.size(); }
+static bool mat_ok(rt_scene* sc, int m) { return m >= 0 && m < (int)sc->s.materials.size(); }
+static bool node_ok(rt_scene* sc, int h) { return h >= 0 && h < (int)sc->s.nodes.size(); }
+static int add_node(rt_scene* sc, const HNode& n) { touch(sc); sc->s.nodes.push_back(n); return (int)sc->s.nodes.size() - 1; }
+static int add_tex(rt_scene* sc, const DTexture<double>& t) { touch(sc); sc->s.textures.push_back(t); return (int)sc->s.textures.size() - 1; }
+static int add_mat(rt_scene* sc, const DMaterial<double>& m) { touch(sc); sc->s.materials.push_back(m); return (int)sc->s.materials.size() - 1; }
+
+int rt_texture_constant(rt_scene* sc, const double rgb[3]) {
+    DTexture<double> t{}; t.kind = T_CONSTANT; t.color[0] = rgb[0]; t.color[1] = rgb[1]; t.color[2] = rgb[2];
+    return add_tex(sc, t);
+}
+int rt_texture_check(rt_scene* sc, int odd, int even) {
+    if (!tex_ok(sc, odd) || !tex_ok(sc, even)) return scene_err(sc, "CheckTexture: bad texture handle");
+    DTexture<double> t{}; t.kind = T_CHECK; t.a = (uint32_t)odd; t.b = (uint32_t)even;
+    return add_tex(sc, t);
+}
+// NoiseTexture::new -> Perlin::new (src/perlin.rs:67-75): generate_vector (:13-19), then generate_perm x3 (:21-37)
+int rt_texture_noise(rt_scene* sc, double scale, rt_rng* rng) {
+    if (!rng) return scene_err(sc, "NoiseTexture: rng is null");
+    HPerlin p;
+    for (int i = 0; i < 256; i++) {
+        for (;;) {                                               // Vec3::random_in_unit_sphere, src/vec.rs:78-85
+            double a = rng_range(rng->r, -1.0, 1.0), b = rng_range(rng->r, -1.0, 1.0), c = rng_range(rng->r, -1.0, 1.0);
+            if (std::sqrt(a * a + b * b + c * c) < 1.0) { p.rd_vec[i * 3] = a; p.rd_vec[i * 3 + 1] = b; p.rd_vec[i * 3 + 2] = c; break; }
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < 256; i++) p.perm[k][i] = (uint8_t)i;
+        for (int i = 255; i >= 0; i--) {
+            uint32_t target = rng_index(rng->r, (uint32_t)i + 1u);   // gen_range(0..=i)
+            uint8_t tmp = p.perm[k][i]; p.perm[k][i] = p.perm[k][target]; p.perm[k][target] = tmp;
+        }
+    }
+    sc->s.perlins.push_back(p);
+    DTexture<double> t{}; t.kind = T_NOISE; t.a = (uint32_t)sc->s.perlins.size() - 1; t.scale = scale;
+    return add_tex(sc, t);
+}
+int rt_texture_image(rt_scene* sc, const uint8_t* rgb8, uint32_t width, uint32_t height) {
+    if (!rgb8 || width == 0 || height == 0) return scene_err(sc, "ImageTexture: empty image");
+    DTexture<double> t{}; t.kind = T_IMAGE; t.a = (uint32_t)sc->s.image_bytes.size(); t.b = width; t.c = height;
+    sc->s.image_bytes.insert(sc->s.image_bytes.end(), rgb8, rgb8 + (size_t)3 * width * height);
+    return add_tex(sc, t);
+}
+
+int rt_material_lambertian(rt_scene* sc, int tex) {
+    if (!tex_ok(sc, tex)) return scene_err(sc, "Lambertian: bad texture handle");
+    DMaterial<double> m{}; m.kind = M_LAMBERTIAN; m.tex = (uint32_t)tex; return add_mat(sc, m);
+}
+int rt_material_metal(rt_scene* sc, const double albedo[3], double fuzz) {
+    DMaterial<double> m{}; m.kind = M_METAL; m.albedo[0] = albedo[0]; m.albedo[1] = albedo[1]; m.albedo[2] = albedo[2]; m.param = fuzz; return add_mat(sc, m);
+}
+int rt_material_dielectric(rt_scene* sc, double ir) { DMaterial<double> m{}; m.kind = M_DIELECTRIC; m.param = ir; return add_mat(sc, m); }
+int rt_material_diffuse_light(rt_scene* sc, int tex) {
+    if (!tex_ok(sc, tex)) return scene_err(sc, "DiffuseLight: bad texture handle");
+    DMaterial<double> m{}; m.kind = M_DIFFUSE_LIGHT; m.tex = (uint32_t)tex; return add_mat(sc, m);
+}
+int rt_material_isotropic(rt_scene* sc, int tex) {
+    if (!tex_ok(sc, tex)) return scene_err(sc, "Isotropic: bad texture handle");
+    DMaterial<double> m{}; m.kind = M_ISOTROPIC; m.tex = (uint32_t)tex; return add_mat(sc, m);
+}
+
+int rt_sphere(rt_scene* sc, const double c[3], double r, int mat) {
+    if (!mat_ok(sc, mat)) return scene_err(sc, "Sphere: bad material handle");
+    HNode n; n.kind = HNode::SPHERE; n.v[0] = c[0]; n.v[1] = c[1]; n.v[2] = c[2]; n.v[3] = r; n.mat = mat; return add_node(sc, n);
+}
+int rt_moving_sphere(rt_scene* sc, const double c0[3], const double c1[3], double t0, double t1, double r, int mat) {
+    if (!mat_ok(sc, mat)) return scene_err(sc, "MovingSphere: bad material handle");
+    HNode n; n.kind = HNode::MSPHERE;
+    for (int k = 0; k < 3; k++) { n.v[k] = c0[k]; n.v[3 + k] = c1[k]; }
+    n.v[6] = t0; n.v[7] = t1; n.v[8] = r; n.mat = mat; return add_node(sc, n);
+}
+int rt_aarect(rt_scene* sc, int plane, double a0, double a1, double b0, double b1, double k, int mat) {
+    if (!mat_ok(sc, mat)) return scene_err(sc, "AARect: bad material handle");
+    if (plane < 0 || plane > 2) return scene_err(sc, "AARect: bad plane");
+    HNode n; n.kind = HNode::RECT; n.v[0] = a0; n.v[1] = a1; n.v[2] = b0; n.v[3] = b1; n.v[4] = k; n.plane_or_axis = plane; n.mat = mat; return add_node(sc, n);
+}
+int rt_cube(rt_scene* sc, const double mn[3], const double mx[3], int mat) {
+    if (!mat_ok(sc, mat)) return scene_err(sc, "Cube: bad material handle");
+    HNode n; n.kind = HNode::CUBE; for (int k = 0; k < 3; k++) { n.v[k] = mn[k]; n.v[3 + k] = mx[k]; } n.mat = mat; return add_node(sc, n);
+}
+int rt_triangle(rt_scene* sc, const double v[9], int mat) {
+    if (!mat_ok(sc, mat)) return scene_err(sc, "Triangle: bad material handle");
+    HNode n; n.kind = HNode::TRI; for (int k = 0; k < 9; k++) n.v[k] = v[k]; n.mat = mat; return add_node(sc, n);
+}
+int rt_list_create(rt_scene* sc) { HNode n; n.kind = HNode::LIST; return add_node(sc, n); }
+int rt_list_push(rt_scene* sc, int list, int h) {
+    if (!node_ok(sc, list) || sc->s.nodes[list].kind != HNode::LIST) return scene_err(sc, "HittableList::push: not a list");
+    if (!node_ok(sc, h)) return scene_err(sc, "HittableList::push: bad hittable handle");
+    touch(sc); sc->s.nodes[list].items.push_back(h); return 0;
+}
+int rt_mesh(rt_scene* sc, const double* positions, uint32_t n_positions, const uint32_t* indices, uint32_t n_indices, int mat) {
+    if (!mat_ok(sc, mat)) return scene_err(sc, "Mesh: bad material handle");
+    for (uint32_t i = 0; i < n_indices; i++) if (indices[i] >= n_positions) return scene_err(sc, "Mesh: index out of range");
+    int list = rt_list_create(sc);
+    for (uint32_t i = 0; i < n_indices / 3; i++) {                    // src/mesh.rs:19-26
+        double v[9];
+        for (int c = 0; c < 3; c++) for (int k = 0; k < 3; k++) v[c * 3 + k] = positions[(size_t)indices[i * 3 + c] * 3 + k];
+        int t = rt_triangle(sc, v, mat);
+        sc->s.nodes[list].items.push_back(t);
+    }
+    return list;
+}
+int rt_flip_normal(rt_scene* sc, int h) {
+    if (!node_ok(sc, h)) return scene_err(sc, "FlipNormal: bad hittable handle");
+    HNode n; n.kind = HNode::FLIP; n.child = h; return add_node(sc, n);
+}
+int rt_translate(rt_scene* sc, int h, const double off[3]) {
+    if (!node_ok(sc, h)) return scene_err(sc, "Translate: bad hittable handle");
+    HNode n; n.kind = HNode::TRANSLATE; n.child = h; n.v[0] = off[0]; n.v[1] = off[1]; n.v[2] = off[2]; return add_node(sc, n);
+}
+int rt_rotate(rt_scene* sc, int axis, int h, double angle) {
+    if (!node_ok(sc, h)) return scene_err(sc, "Rotate: bad hittable handle");
+    if (axis < 0 || axis > 2) return scene_err(sc, "Rotate: bad axis");
+    HNode n; n.kind = HNode::ROTATE; n.child = h; n.plane_or_axis = axis; n.v[0] = angle; return add_node(sc, n);
+}
+int rt_constant_medium(rt_scene* sc, int boundary, double density, int tex) {
+    if (!node_ok(sc, boundary)) return scene_err(sc, "ConstantMedium: bad boundary handle");
+    if (!tex_ok(sc, tex)) return scene_err(sc, "ConstantMedium: bad texture handle");
+    HNode n; n.kind = HNode::MEDIUM; n.child = boundary; n.v[0] = density; n.mat = tex; return add_node(sc, n);
+}
+int rt_bvh(rt_scene* sc, const int* hs, uint32_t nh, double, double) {
+    if (nh == 0) return scene_err(sc, "no object in the scene");                 // src/bvh.rs:55 panics
+    HNode n; n.kind = HNode::BVH;
+    for (uint32_t i = 0; i < nh; i++) { if (!node_ok(sc, hs[i])) return scene_err(sc, "BVH: bad hittable handle"); n.items.push_back(hs[i]); }
+    return add_node(sc, n);
+}
+int rt_bvh_of_list(rt_scene* sc, int list, double t0, double t1) {
+    if (!node_ok(sc, list) || sc->s.nodes[list].kind != HNode::LIST) return scene_err(sc, "BVH: not a list");
+    std::vector<int> items = sc->s.nodes[list].items;
+    return rt_bvh(sc, items.data(), (uint32_t)items.size(), t0, t1);
+}
+int rt_scene_set_world(rt_scene* sc, int h) {
+    if (!node_ok(sc, h)) return scene_err(sc, "set_world: bad hittable handle");
+    touch(sc); sc->s.world = h; return 0;
+}
+int rt_lights_push(rt_scene* sc, int h) {
+    if (!node_ok(sc, h)) return scene_err(sc, "lights.push: bad hittable handle");
+    touch(sc); sc->s.lights.push_back(h); return 0;
+}
+
+// ---------------------------------------------------------------- host-side boundary pieces
+void rt_camera_fields(const rt_camera* c, double out21[21]) {
+    rt_camera_args a; std::memcpy(&a, c, sizeof(a));
+    DCamera<double> d; camera_new(a, d);
+    const double* vs[6] = {d.origin, d.lower_left_corner, d.horizontal, d.vertical, d.cu, d.cv};
+    for (int i = 0; i < 6; i++) for (int k = 0; k < 3; k++) out21[i * 3 + k] = vs[i][k];
+    out21[18] = d.lens_radius; out21[19] = d.time0; out21[20] = d.time1;
+}
+// Vec3::format_color, src/vec.rs:125-131: (256.0 * (c / spp).sqrt().clamp(0.0, 0.999)) as u64
+void rt_format_color(const double rgb_sum[3], uint64_t spp, uint64_t out3[3]) {
+    for (int k = 0; k < 3; k++) {
+        double x = std::sqrt(rgb_sum[k] / (double)spp);
+        if (x < 0.0) x = 0.0; else if (x > 0.999) x = 0.999;       // f64::clamp: NaN stays NaN
+        double y = 256.0 * x;
+        out3[k] = (y > 0.0) ? (y >= 18446744073709551616.0 ? UINT64_MAX : (uint64_t)y) : 0;   // `as u64` saturates, NaN -> 0
+    }
+}
+int rt_write_ppm(const char* path, const double* rgb_sum, uint32_t W, uint32_t H, uint64_t spp) {
+    FILE* f = (!path || std::strcmp(path, "-") == 0) ? stdout : std::fopen(path, "w");
+    if (!f) return set_err(std::string("cannot open ") + path);
+    std::fprintf(f, "P3\n%u %u\n255\n", W, H);                      // src/main.rs:767-769
+    for (size_t p = 0; p < (size_t)W * H; p++) {
+        uint64_t c[3]; rt_format_color(rgb_sum + p * 3, spp, c);
+        std::fprintf(f, "%llu %llu %llu\n", (unsigned long long)c[0], (unsigned long long)c[1], (unsigned long long)c[2]);   // src/main.rs:832
+    }
+    if (f != stdout) std::fclose(f); else std::fflush(f);
+    return 0;
+}
+
+int rt_scene_flatten(rt_scene* sc, uint32_t counts[12]) {
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    const HostFlat& f = sc->s.flat;
+    if (counts) {
+        uint32_t c[12] = {(uint32_t)f.objects.size(), (uint32_t)f.ops.size(), (uint32_t)f.rects.size(), (uint32_t)f.spheres.size(),
+                          (uint32_t)f.mspheres.size(), (uint32_t)f.tris.size(), (uint32_t)f.bvh.size(), (uint32_t)f.materials.size(),
+                          (uint32_t)f.textures.size(), (uint32_t)f.lights.size(), (uint32_t)f.media.size(), (uint32_t)sc->s.perlins.size()};
+        std::memcpy(counts, c, sizeof(c));
+    }
+    return 0;
+}
+
+uint32_t rt_local_tiles(uint32_t W, uint32_t H, uint32_t tile_px, uint32_t rank, uint32_t world) {
+    (void)rank;
+    if (tile_px == 0 || world == 0) return 0;
+    uint64_t n_px = (uint64_t)W * H;
+    uint64_t n_tiles = (n_px + tile_px - 1) / tile_px;
+    return (uint32_t)((n_tiles + world - 1) / world);       // padded: identical on every rank
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------- device upload
+namespace {
+
+template <typename T> void cv(const DRect<double>& a, DRect<T>& b) { b.a0 = (T)a.a0; b.a1 = (T)a.a1; b.b0 = (T)a.b0; b.b1 = (T)a.b1; b.k = (T)a.k; b.plane = a.plane; b.mat = a.mat; }
+template <typename T> void cv(const DSphere<double>& a, DSphere<T>& b) { for (int k = 0; k < 3; k++) b.c[k] = (T)a.c[k]; b.r = (T)a.r; b.mat = a.mat; b.pad = 0; }
+template <typename T> void cv(const DMSphere<double>& a, DMSphere<T>& b) { for (int k = 0; k < 3; k++) { b.c0[k] = (T)a.c0[k]; b.c1[k] = (T)a.c1[k]; } b.t0 = (T)a.t0; b.t1 = (T)a.t1; b.r = (T)a.r; b.mat = a.mat; b.pad = 0; }
+template <typename T> void cv(const DTri<double>& a, DTri<T>& b) { for (int k = 0; k < 3; k++) { b.v0[k] = (T)a.v0[k]; b.e1[k] = (T)a.e1[k]; b.e2[k] = (T)a.e2[k]; } b.mat = a.mat; b.pad = 0; }
+template <typename T> void cv(const DOp<double>& a, DOp<T>& b) { b.kind = a.kind; b.axis = a.axis; b.x = (T)a.x; b.y = (T)a.y; b.z = (T)a.z; }
+template <typename T> void cv(const DBvhNode<double>& a, DBvhNode<T>& b) { for (int k = 0; k < 3; k++) { b.mn[k] = (T)a.mn[k]; b.mx[k] = (T)a.mx[k]; } b.a = a.a; b.b = a.b; }
+template <typename T> void cv(const DMaterial<double>& a, DMaterial<T>& b) { b.kind = a.kind; b.tex = a.tex; for (int k = 0; k < 3; k++) b.albedo[k] = (T)a.albedo[k]; b.param = (T)a.param; }
+template <typename T> void cv(const DTexture<double>& a, DTexture<T>& b) { b.kind = a.kind; b.a = a.a; b.b = a.b; b.c = a.c; for (int k = 0; k < 3; k++) b.color[k] = (T)a.color[k]; b.scale = (T)a.scale; }
+template <typename T> void cv(const DMedium<double>& a, DMedium<T>& b) { b.neg_inv_density = (T)a.neg_inv_density; b.mat = a.mat; b.pad = 0; }
+
+template <typename DT, typename ST> int upload_vec(const std::vector<ST>& src, void*& dst) {
+    dst = nullptr;
+    size_t n = src.size();
+    std::vector<DT> tmp(n ? n : 1);
+    std::memset((void*)tmp.data(), 0, tmp.size() * sizeof(DT));
+    for (size_t i = 0; i < n; i++) cv(src[i], tmp[i]);
+    HIP_OK(hipMalloc(&dst, tmp.size() * sizeof(DT)));
+    HIP_OK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(DT), hipMemcpyHostToDevice));
+    return 0;
+}
+template <typename PT> int upload_raw(const std::vector<PT>& src, void*& dst) {
+    dst = nullptr;
+    size_t bytes = (src.size() ? src.size() : 1) * sizeof(PT);
+    HIP_OK(hipMalloc(&dst, bytes));
+    if (!src.empty()) HIP_OK(hipMemcpy(dst, src.data(), src.size() * sizeof(PT), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
+    if (d.valid) return 0;
+    const HostFlat& f = s.flat;
+    if (upload_raw(f.objects, d.objects)) return -1;
+    if (upload_vec<DOp<T>>(f.ops, d.ops)) return -1;
+    if (upload_vec<DRect<T>>(f.rects, d.rects)) return -1;
+    if (upload_vec<DSphere<T>>(f.spheres, d.spheres)) return -1;
+    if (upload_vec<DMSphere<T>>(f.mspheres, d.mspheres)) return -1;
+    if (upload_vec<DTri<T>>(f.tris, d.tris)) return -1;
+    if (upload_vec<DBvhNode<T>>(f.bvh, d.bvh)) return -1;
+    if (upload_vec<DMaterial<T>>(f.materials, d.materials)) return -1;
+    if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
+    if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
+    if (upload_raw(f.lights, d.lights)) return -1;
+    std::vector<DPerlin<T>> pl(s.perlins.size());
+    for (size_t i = 0; i < pl.size(); i++) {
+        for (int k = 0; k < 768; k++) pl[i].rd_vec[k] = (T)s.perlins[i].rd_vec[k];
+        std::memcpy(pl[i].perm_x, s.perlins[i].perm[0], 256);
+        std::memcpy(pl[i].perm_y, s.perlins[i].perm[1], 256);
+        std::memcpy(pl[i].perm_z, s.perlins[i].perm[2], 256);
+    }
+    if (upload_raw(pl, d.perlins)) return -1;
+    if (upload_raw(s.image_bytes, d.image)) return -1;
+    d.valid = true;
+    return 0;
+}
+
+template <typename T> DeviceScene<T>& dev_of(Scene& s);
+template <> DeviceScene<double>& dev_of<double>(Scene& s) { return s.dev64; }
+template <> DeviceScene<float>& dev_of<float>(Scene& s) { return s.dev32; }
+
+template <typename T>
+int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
+                void* d_samples, hipStream_t stream) {
+    DeviceScene<T>& d = dev_of<T>(s);
+    if (ensure_uploaded<T>(s, d)) return -1;
+    const HostFlat& f = s.flat;
+    KParams<T> P;
+    std::memset((void*)&P, 0, sizeof(P));
+    P.objects = (const DObject*)d.objects; P.n_objects = (uint32_t)f.objects.size();
+    P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
+    P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
+    P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
+    P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
+    P.perlins = (const DPerlin<T>*)d.perlins; P.image_bytes = (const uint8_t*)d.image;
+    P.stack_depth = f.bvh_depth;
+    rt_camera_args ca; std::memcpy(&ca, camp, sizeof(ca));
+    DCamera<double> cam; camera_new(ca, cam);
+    for (int k = 0; k < 3; k++) {
+        P.cam.origin[k] = (T)cam.origin[k]; P.cam.lower_left_corner[k] = (T)cam.lower_left_corner[k];
+        P.cam.horizontal[k] = (T)cam.horizontal[k]; P.cam.vertical[k] = (T)cam.vertical[k];
+        P.cam.cu[k] = (T)cam.cu[k]; P.cam.cv[k] = (T)cam.cv[k]; P.background[k] = (T)bg[k];
+    }
+    P.cam.lens_radius = (T)cam.lens_radius; P.cam.time0 = (T)cam.time0; P.cam.time1 = (T)cam.time1;
+    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = flags;
+    P.tile_px = tile_px; P.rank = rank; P.world = world;
+    P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
+    uint64_t n_local_px = (uint64_t)P.n_local_tiles * tile_px;
+    if (n_local_px >= 0xFFFFFFFFull) return set_err("too many local pixels");
+    if ((size_t)n_local_px * 3 * sizeof(double) > d_out_bytes) return set_err("output buffer too small for n_local_tiles * tile_px * 3 doubles");
+    P.chunk_px = spp >= 256 ? 1u : (256u + spp - 1) / spp;
+    P.n_chunks = (uint32_t)((n_local_px + P.chunk_px - 1) / P.chunk_px);
+    if (!s.d_queue) HIP_OK(hipMalloc(&s.d_queue, 64));
+    if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 64));
+    if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
+    if (!s.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_stop = e; }
+    P.queue = (uint32_t*)s.d_queue; P.stats = (unsigned long long*)s.d_stats;
+    P.out = (double*)d_out; P.samples_out = (double*)d_samples;
+
+    int dev = 0; HIP_OK(hipGetDevice(&dev));
+    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, dev));
+    size_t shmem = (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
+    int bpc = pathtrace_blocks_per_cu<T>(f.feats, shmem);
+    if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
+    uint64_t waves_needed = (n_local_px * spp + 63) / 64;
+    uint64_t blocks_needed = (waves_needed + 3) / 4;
+    uint64_t n_blocks = (uint64_t)prop.multiProcessorCount * (uint64_t)bpc;
+    if (n_blocks > blocks_needed) n_blocks = blocks_needed;
+    if (n_blocks == 0) n_blocks = 1;
+
+    HIP_OK(hipMemsetAsync(s.d_queue, 0, 64, stream));
+    HIP_OK(hipMemsetAsync(s.d_stats, 0, 64, stream));
+    HIP_OK(hipMemsetAsync(d_out, 0, (size_t)n_local_px * 3 * sizeof(double), stream));
+    HIP_OK(hipEventRecord((hipEvent_t)s.ev_start, stream));
+    HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
+    HIP_OK(hipEventRecord((hipEvent_t)s.ev_stop, stream));
+    s.ev_recorded = true;
+    return 0;
+}
+
+int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+               uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
+               void* d_samples, hipStream_t stream) {
+    if (!sc || !cam || !bg) return set_err("null argument");
+    if (W < 2 || H < 2) return set_err("W and H must be >= 2 (u,v divide by W-1 and H-1, src/main.rs:817-818)");
+    if (spp == 0) return set_err("samples_per_pixel must be >= 1");
+    if (tile_px == 0 || world == 0 || rank >= world) return set_err("bad tile decomposition");
+    if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    if (flags & RT_F32) return render_impl<float>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
+    return render_impl<double>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
+}
+
+} // namespace
+
+extern "C" {
+
+int rt_render_device(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                     uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes, void* hip_stream) {
+    return render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, nullptr, (hipStream_t)hip_stream);
+}
+
+int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
+    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
+    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
+    HIP_OK(hipEventElapsedTime(ms_out, (hipEvent_t)sc->s.ev_start, (hipEvent_t)sc->s.ev_stop));
+    return 0;
+}
+
+// [0] non-finite samples, [1] wave bounce-loop iterations, [2] lane-iterations with a live path  (last finished launch)
+int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {
+    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
+    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
+    HIP_OK(hipMemcpy(out, sc->s.d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rt_render_samples(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                      uint64_t seed, uint32_t flags, double* rgb_sum_out, double* samples_out) {
+    if (!rgb_sum_out) return set_err("null output");
+    size_t n_px = (size_t)W * H;
+    void* d_out = nullptr; void* d_samples = nullptr;
+    if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
+    HIP_OK(hipMalloc(&d_out, n_px * 3 * sizeof(double)));
+    if (samples_out) {
+        hipError_t e = hipMalloc(&d_samples, n_px * spp * 3 * sizeof(double));
+        if (e != hipSuccess) { (void)hipFree(d_out); return set_err(std::string("hipMalloc(samples): ") + hipGetErrorString(e)); }
+    }
+    int rc = render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, (uint32_t)n_px, 0, 1, d_out, n_px * 3 * sizeof(double), d_samples, nullptr);
+    if (rc == 0) {
+        hipError_t e = hipStreamSynchronize(nullptr);
+        if (e == hipSuccess) e = hipMemcpy(rgb_sum_out, d_out, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && samples_out) e = hipMemcpy(samples_out, d_samples, n_px * spp * 3 * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { g_err = std::string("copy back: ") + hipGetErrorString(e); rc = -1; }
+    }
+    (void)hipFree(d_out);
+    if (d_samples) (void)hipFree(d_samples);
+    return rc;
+}
+
+int rt_render(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+              uint64_t seed, uint32_t flags, double* rgb_sum_out) {
+    return rt_render_samples(sc, cam, bg, W, H, spp, max_depth, seed, flags, rgb_sum_out, nullptr);
+}
+
+} // extern "C"

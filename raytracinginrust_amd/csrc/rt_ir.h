@@ -1,0 +1,93 @@
+// csrc/rt_ir.h — the flat device scene ("IR") the host flattener produces and the kernels read.
+//
+// The reference scene is a tree of `Box<dyn Hittable>` with `&dyn Material` / `dyn Texture` leaves
+// (src/hit.rs:26-31, src/mat.rs:54-77, src/texture.rs:5-7).  On the GPU every `dyn` becomes a small
+// integer tag and every Box a table index:
+//
+//   world  = objects[0..n_objects)   in HittableList push order (src/hit.rs:59-71)
+//   object = wrapper chain ops[first_op .. first_op+n_ops) outermost first (Translate / Rotate / FlipNormal),
+//            optional ConstantMedium (outermost only), and one geometry:
+//              a typed range of primitives (1 rect, 6 rects = Cube, n triangles = Mesh list, ...) or a BVH root
+//   BVH    = nodes in DFS preorder: left child = node + 1, right child stored; leaves hold a typed
+//            primitive range (a sphere, a moving sphere, a triangle, or a Cube's 6 rects)
+//   lights = light records (rect / sphere / "other" = trait default pdf 0, random (1,0,0))
+//
+// Records are templated on the arithmetic type: the f64 build is the reference-precision product path,
+// the f32 build the throughput variant.  Top-level tables are read with wave-uniform indices (scalar
+// loads); BVH nodes and leaf primitives with per-lane indices (vector gathers, node = one 64-byte line
+// in f64).
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+enum GeomKind : uint32_t { G_RECT = 0, G_SPHERE = 1, G_MSPHERE = 2, G_TRI = 3, G_BVH = 4 };
+enum OpKind : uint32_t { OP_TRANSLATE = 0, OP_ROTATE = 1, OP_FLIP = 2 };
+enum MatKind : uint32_t { M_LAMBERTIAN = 0, M_METAL = 1, M_DIELECTRIC = 2, M_DIFFUSE_LIGHT = 3, M_ISOTROPIC = 4 };
+enum TexKind : uint32_t { T_CONSTANT = 0, T_CHECK = 1, T_NOISE = 2, T_IMAGE = 3 };
+enum LightKind : uint32_t { L_RECT = 0, L_SPHERE = 1, L_OTHER = 2 };
+
+// scene feature bits: the host picks the leanest kernel instantiation that covers the scene
+enum Feat : uint32_t {
+    F_BVH = 1u << 0,        // any G_BVH geometry
+    F_SPHERES = 1u << 1,    // spheres / moving spheres
+    F_TRIS = 1u << 2,       // triangles
+    F_MEDIUM = 1u << 3,     // ConstantMedium
+    F_TEXTURES = 1u << 4,   // Check / Noise / Image textures
+    F_DIELECTRIC = 1u << 5, // Dielectric material
+    F_ALL = 0x3F
+};
+
+static const uint32_t BVH_LEAF = 0x80000000u;     // node.a: bit 31 leaf, bits 28..30 GeomKind, bits 0..27 first index
+static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
+static const int RT_MAX_BVH_DEPTH = 48;
+
+template <typename T> struct DRect { T a0, a1, b0, b1, k; uint32_t plane, mat; };            // src/rect.rs:16-24
+template <typename T> struct DSphere { T c[3], r; uint32_t mat, pad; };                       // src/sphere.rs:38-43
+template <typename T> struct DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
+template <typename T> struct DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
+template <typename T> struct DOp { uint32_t kind, axis; T x, y, z; };                         // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
+struct DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
+template <typename T> struct DBvhNode { T mn[3], mx[3]; uint32_t a, b; };                     // f64: 56 B -> padded to 64
+template <typename T> struct DMaterial { uint32_t kind, tex; T albedo[3]; T param; };         // metal: albedo, fuzz; dielectric: param = ir
+template <typename T> struct DTexture { uint32_t kind, a, b, c; T color[3]; T scale; };       // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height
+template <typename T> struct DMedium { T neg_inv_density; uint32_t mat, pad; };               // -(1.0/density), src/medium.rs:42
+struct DLight { uint32_t kind, index; };
+template <typename T> struct DPerlin { T rd_vec[256 * 3]; uint8_t perm_x[256], perm_y[256], perm_z[256]; };   // src/perlin.rs:59-65
+template <typename T> struct DCamera {                                                        // src/camera.rs:6-16
+    T origin[3], lower_left_corner[3], horizontal[3], vertical[3], cu[3], cv[3];
+    T lens_radius, time0, time1;
+};
+
+template <typename T> struct KParams {
+    // scene
+    const DObject* objects; uint32_t n_objects;
+    const DOp<T>* ops;
+    const DRect<T>* rects;
+    const DSphere<T>* spheres;
+    const DMSphere<T>* mspheres;
+    const DTri<T>* tris;
+    const DBvhNode<T>* bvh;
+    const DMaterial<T>* materials;
+    const DTexture<T>* textures;
+    const DMedium<T>* media;
+    const DLight* lights; uint32_t n_lights;
+    const DPerlin<T>* perlins;
+    const uint8_t* image_bytes;
+    uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS
+    // frame
+    DCamera<T> cam;
+    T background[3];
+    uint32_t W, H, spp, max_depth;
+    uint64_t seed;
+    uint32_t flags;
+    // work decomposition: this launch owns tiles t = rank + q*world, q in [0, n_local_tiles)
+    uint32_t tile_px, rank, world, n_local_tiles;
+    uint32_t chunk_px, n_chunks;   // dequeue unit over the local pixel space
+    uint32_t* queue;               // zeroed before launch
+    double* out;                   // n_local_tiles * tile_px * 3 (always f64: per-pixel sums)
+    double* samples_out;           // optional: local_px * spp * 3
+    unsigned long long* stats;     // [0] non-finite samples, [1] bounce iterations, [2] lane-iterations active
+};
+
+} // namespace rt

@@ -1,0 +1,759 @@
+// csrc/rt_kernel.hip — the per-pixel sample loop of 4meame/RayTracingInRust as one persistent HIP kernel
+// for gfx950 (MI355X).  Replaces src/main.rs:772-833 (+ everything ray_color reaches).
+//
+// Shape of the kernel (not a translation of the reference's rayon loop):
+//   * work unit = one camera path (pixel, sample).  A wavefront (64 lanes) pulls whole pixels from a global
+//     queue (one atomic per chunk) and hands samples to its lanes.  Whenever lanes' paths end (miss, light,
+//     absorbed, depth), `__ballot` + `mbcnt` prefix ranks give every dead lane the next sample index
+//     ("compaction by regeneration"): the wave never drains between pixels, lanes stay full until the
+//     queue is empty.
+//   * the reference's recursion `e + w * ray_color(child)` (src/main.rs:41-120) is linear, so it runs as an
+//     in-kernel bounce loop carrying the throughput `beta`; radiance is added when the path terminates.
+//   * top-level objects (HittableList push order) are walked with wave-uniform indices -> scalar loads, no
+//     VGPR cost; only (t, object, primitive) of the closest hit is kept and the hit record is rebuilt once
+//     per bounce with per-lane gathers.  BVH traversal is per-lane with its stack staged in LDS.
+//   * per-pixel sums stay in registers (one accumulator per lane) and are combined with a segmented
+//     wave reduction when a lane moves to another pixel; one owner wave per pixel, so no float atomics.
+//   * no MFMA: there is no dense contraction anywhere on this path.
+//
+// Arithmetic follows the reference expression by expression (cited inline) and is compiled with
+// -ffp-contract=off, so in f64 every +,-,*,/ and sqrt rounds exactly like the CPU; only libm-class
+// functions (sin, cos, atan2, acos, log) may differ from a host libm in the last ulp.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rt_ir.h"
+#include "rt_rng.h"
+#include "rt_launch.h"
+
+namespace rt {
+
+// ------------------------------------------------------------------ small vector algebra (src/vec.rs)
+template <typename T> struct V3 { T x, y, z; };
+#define DEV __device__ __forceinline__
+template <typename T> DEV V3<T> mk(T x, T y, T z) { V3<T> v; v.x = x; v.y = y; v.z = z; return v; }
+template <typename T> DEV V3<T> operator+(V3<T> a, V3<T> b) { return mk<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> DEV V3<T> operator-(V3<T> a, V3<T> b) { return mk<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> DEV V3<T> operator*(V3<T> a, V3<T> b) { return mk<T>(a.x * b.x, a.y * b.y, a.z * b.z); }
+template <typename T> DEV V3<T> operator*(V3<T> a, T s) { return mk<T>(a.x * s, a.y * s, a.z * s); }
+template <typename T> DEV V3<T> operator*(T s, V3<T> a) { return mk<T>(s * a.x, s * a.y, s * a.z); }
+template <typename T> DEV V3<T> operator/(V3<T> a, T s) { return mk<T>(a.x / s, a.y / s, a.z / s); }
+template <typename T> DEV T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                  // vec.rs:38-40
+template <typename T> DEV V3<T> cross(V3<T> a, V3<T> b) { return mk<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }   // vec.rs:46-54
+DEV double rsqrt_(double x) { return ::sqrt(x); }
+DEV float rsqrt_(float x) { return ::sqrtf(x); }
+template <typename T> DEV T length(V3<T> a) { return rsqrt_(dot(a, a)); }                                           // vec.rs:42-44
+template <typename T> DEV V3<T> normalized(V3<T> a) { return a / length(a); }                                       // vec.rs:56-58
+template <typename T> DEV T sq_of_len(V3<T> a) { T l = length(a); return l * l; }                                   // `.length().powi(2)`
+template <typename T> DEV T get(V3<T> v, uint32_t k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
+template <typename T> DEV V3<T> ld3(const T* p) { return mk<T>(p[0], p[1], p[2]); }
+
+DEV double m_sin(double x) { return ::sin(x); }   DEV float m_sin(float x) { return ::sinf(x); }
+DEV double m_cos(double x) { return ::cos(x); }   DEV float m_cos(float x) { return ::cosf(x); }
+DEV double m_log(double x) { return ::log(x); }   DEV float m_log(float x) { return ::logf(x); }
+DEV double m_acos(double x) { return ::acos(x); } DEV float m_acos(float x) { return ::acosf(x); }
+DEV double m_atan2(double y, double x) { return ::atan2(y, x); } DEV float m_atan2(float y, float x) { return ::atan2f(y, x); }
+DEV double m_floor(double x) { return ::floor(x); } DEV float m_floor(float x) { return ::floorf(x); }
+DEV double m_abs(double x) { return ::fabs(x); }  DEV float m_abs(float x) { return ::fabsf(x); }
+DEV double m_max(double a, double b) { return ::fmax(a, b); } DEV float m_max(float a, float b) { return ::fmaxf(a, b); }   // f64::max: NaN-ignoring
+DEV double m_min(double a, double b) { return ::fmin(a, b); } DEV float m_min(float a, float b) { return ::fminf(a, b); }
+
+template <typename T> struct Lim;
+template <> struct Lim<double> { static DEV double max() { return 1.7976931348623157e308; } static DEV double inf() { return __longlong_as_double(0x7FF0000000000000LL); } };
+template <> struct Lim<float> { static DEV float max() { return 3.402823466e38f; } static DEV float inf() { return __uint_as_float(0x7F800000u); } };
+#define PI_T T(3.14159265358979323846264338327950288)
+
+template <typename T> struct RayT { V3<T> o, d; T tm; };
+template <typename T> DEV V3<T> ray_at(const RayT<T>& r, T t) { return r.o + t * r.d; }                             // ray.rs:26-28
+
+template <typename T> struct Rec {                                                                                 // hit.rs:9-24
+    V3<T> p, n; T t, u, v; bool front; uint32_t mat;
+};
+template <typename T> DEV void set_face_normal(Rec<T>& rec, V3<T> dir, V3<T> outward) {                            // hit.rs:34-41
+    rec.front = dot(dir, outward) < T(0);
+    rec.n = rec.front ? outward : T(-1.0) * outward;
+}
+
+// ------------------------------------------------------------------ primitive tests (closest-hit search keeps only t)
+DEV void plane_axes(uint32_t plane, uint32_t& ki, uint32_t& ai, uint32_t& bi) {                                    // rect.rs:26-32
+    ki = 2u - plane; ai = (plane == 2u) ? 1u : 0u; bi = (plane == 0u) ? 1u : 2u;
+}
+template <typename T> DEV bool rect_test(const DRect<T>& r, const RayT<T>& ray, T t_min, T t_max, T& t_out) {      // rect.rs:49-60
+    uint32_t ki, ai, bi; plane_axes(r.plane, ki, ai, bi);
+    T t = (r.k - get(ray.o, ki)) / get(ray.d, ki);
+    if (t < t_min || t > t_max) return false;
+    T a = get(ray.o, ai) + t * get(ray.d, ai);
+    T b = get(ray.o, bi) + t * get(ray.d, bi);
+    if (a < r.a0 || a > r.a1 || b < r.b0 || b > r.b1) return false;
+    t_out = t;
+    return true;
+}
+template <typename T> DEV bool sphere_test(V3<T> center, T radius, const RayT<T>& ray, T t_min, T t_max, T& t_out) {   // sphere.rs:56-74
+    V3<T> oc = ray.o - center;
+    T a = sq_of_len(ray.d);
+    T half_b = dot(oc, ray.d);
+    T c = sq_of_len(oc) - radius * radius;
+    T discriminant = half_b * half_b - a * c;
+    if (discriminant < T(0)) return false;
+    T sqrt_d = rsqrt_(discriminant);
+    T root = (-half_b - sqrt_d) / a;
+    if (root < t_min || root > t_max) {
+        root = (-half_b + sqrt_d) / a;
+        if (root < t_min || root > t_max) return false;
+    }
+    t_out = root;
+    return true;
+}
+template <typename T> DEV V3<T> msphere_center(const DMSphere<T>& s, T time) {                                      // sphere.rs:144-146
+    return ld3(s.c0) + (time - s.t0) / (s.t1 - s.t0) * (ld3(s.c1) - ld3(s.c0));
+}
+template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T t_min, T t_max, T& t_out, T& b1o, T& b2o) {   // tri.rs:24-41
+    V3<T> s = ray.o - ld3(tr.v0);
+    V3<T> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+    V3<T> s1 = cross(ray.d, e2);
+    V3<T> s2 = cross(s, e1);
+    T s1_e1 = dot(s1, e1);
+    T t = dot(s2, e2) / s1_e1;
+    T b1 = dot(s1, s) / s1_e1;
+    T b2 = dot(s2, ray.d) / s1_e1;
+    if (t < t_min || t > t_max) return false;
+    if (b1 < T(0) || b2 < T(0) || (T(1.0) - b1 - b2) < T(0)) return false;
+    t_out = t; b1o = b1; b2o = b2;
+    return true;
+}
+
+// closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
+// offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
+template <typename T, uint32_t FEATS>
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+    bool any = false;
+    T closest = t_max;
+    if (kind == G_RECT) {
+        for (uint32_t i = first; i < first + count; i++) {
+            T t;
+            if (rect_test(P.rects[i], ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
+        }
+    } else if ((FEATS & F_SPHERES) && kind == G_SPHERE) {
+        for (uint32_t i = first; i < first + count; i++) {
+            T t; const DSphere<T>& s = P.spheres[i];
+            if (sphere_test(ld3(s.c), s.r, ray, t_min, closest, t)) { closest = t; prim_out = (G_SPHERE << 28) | i; any = true; }
+        }
+    } else if ((FEATS & F_SPHERES) && kind == G_MSPHERE) {
+        for (uint32_t i = first; i < first + count; i++) {
+            T t; const DMSphere<T>& s = P.mspheres[i];
+            if (sphere_test(msphere_center(s, ray.tm), s.r, ray, t_min, closest, t)) { closest = t; prim_out = (G_MSPHERE << 28) | i; any = true; }
+        }
+    } else if ((FEATS & F_TRIS) && kind == G_TRI) {
+        for (uint32_t i = first; i < first + count; i++) {
+            T t, b1, b2;
+            if (tri_test(P.tris[i], ray, t_min, closest, t, b1, b2)) { closest = t; prim_out = (G_TRI << 28) | i; any = true; }
+        }
+    }
+    t_out = closest;
+    return any;
+}
+
+// BVH::hit, bvh.rs:77-91: bbox test, then left subtree, then right subtree with t_max shrunk to the left hit.
+// The recursion's t_max at any node equals min(original t_max, closest hit found earlier in DFS order), so one
+// running `closest` with an explicit stack (staged in LDS, one dword column per lane) is the same search.
+// AABB::hit (aabb.rs:19-36) recomputes 1/d per node; the value is the same every time, so it is hoisted.
+template <typename T, uint32_t FEATS>
+DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
+    V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
+    T closest = t_max;
+    bool any = false;
+    uint32_t node = root;
+    uint32_t sp = 0;
+    for (;;) {
+        const DBvhNode<T> nd = P.bvh[node];
+        bool inside = true;
+        {
+            T t_in = t_min, t_o = closest;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                T inv_d = a == 0 ? inv.x : (a == 1 ? inv.y : inv.z);
+                T org = a == 0 ? ray.o.x : (a == 1 ? ray.o.y : ray.o.z);
+                T t0 = (nd.mn[a] - org) * inv_d;
+                T t1 = (nd.mx[a] - org) * inv_d;
+                if (inv_d < T(0)) { T tmp = t0; t0 = t1; t1 = tmp; }
+                t_in = m_max(t_in, t0);
+                t_o = m_min(t_o, t1);
+                if (t_o <= t_in) inside = false;    // aabb.rs:31-33 returns here; later axes cannot un-fail it
+            }
+        }
+        if (inside) {
+            if (nd.a & BVH_LEAF) {
+                T t; uint32_t prim;
+                if (range_hit<T, FEATS>(P, (nd.a >> 28) & 7u, nd.a & 0x0FFFFFFFu, nd.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
+            } else {
+                stack[sp * 64u] = nd.b;     // right child waits; left child is the next node in preorder
+                sp++;
+                node = nd.a;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        node = stack[sp * 64u];
+    }
+    t_out = closest;
+    return any;
+}
+
+// ------------------------------------------------------------------ wrapper chain (translate.rs, rotate.rs, hit.rs FlipNormal)
+template <typename T> DEV void rot_fwd(uint32_t axis, T sn, T cs, V3<T>& v) {       // rotate.rs:82-86
+    T a, b;
+    if (axis == 1u) { a = v.x; b = v.z; v.x = cs * a - sn * b; v.z = sn * a + cs * b; }
+    else if (axis == 0u) { a = v.y; b = v.z; v.y = cs * a - sn * b; v.z = sn * a + cs * b; }
+    else { a = v.x; b = v.y; v.x = cs * a - sn * b; v.y = sn * a + cs * b; }
+}
+template <typename T> DEV void rot_back(uint32_t axis, T sn, T cs, V3<T>& v) {      // rotate.rs:95-99
+    T a, b;
+    if (axis == 1u) { a = v.x; b = v.z; v.x = cs * a + sn * b; v.z = (-sn) * a + cs * b; }
+    else if (axis == 0u) { a = v.y; b = v.z; v.y = cs * a + sn * b; v.z = (-sn) * a + cs * b; }
+    else { a = v.x; b = v.y; v.x = cs * a + sn * b; v.y = (-sn) * a + cs * b; }
+}
+template <typename T> DEV void op_fwd(const DOp<T>& op, RayT<T>& r) {
+    if (op.kind == OP_TRANSLATE) { r.o = r.o - mk<T>(op.x, op.y, op.z); }           // translate.rs:23
+    else if (op.kind == OP_ROTATE) { rot_fwd(op.axis, op.x, op.y, r.o); rot_fwd(op.axis, op.x, op.y, r.d); }
+}
+
+// ------------------------------------------------------------------ world.hit: closest hit over the top-level list
+struct HitId { uint32_t obj, prim; };   // prim: GeomKind << 28 | index, or PRIM_MEDIUM
+static const uint32_t PRIM_MEDIUM = 0xFFFFFFFFu;
+
+template <typename T, uint32_t FEATS>
+DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack) {
+    if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) return bvh_hit<T, FEATS>(P, ob.geom_first, r, t_min, t_max, t, prim, stack);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim);
+}
+
+template <typename T, uint32_t FEATS>
+DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack) {
+    T closest = Lim<T>::inf();
+    bool any = false;
+    for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
+        const DObject ob = P.objects[oi];
+        RayT<T> r = ray;
+        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(P.ops[ob.first_op + k], r);
+        if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
+            T t; uint32_t prim;
+            if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        } else {
+            // ConstantMedium::hit, medium.rs:27-61
+            T t1, t2; uint32_t p1, p2;
+            if (geom_hit<T, FEATS>(P, ob, r, -Lim<T>::max(), Lim<T>::max(), t1, p1, stack)) {
+                if (geom_hit<T, FEATS>(P, ob, r, t1 + T(0.0001), Lim<T>::max(), t2, p2, stack)) {
+                    if (t1 < t_min) t1 = t_min;
+                    if (t2 > closest) t2 = closest;
+                    if (t1 < t2) {
+                        T len = length(ray.d);
+                        T distance_inside_boundary = (t2 - t1) * len;
+                        T hit_distance = P.media[ob.medium].neg_inv_density * m_log(rng_u01(rng, T(0)));
+                        if (hit_distance < distance_inside_boundary) {
+                            closest = t1 + hit_distance / len;
+                            id.obj = oi; id.prim = PRIM_MEDIUM; any = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    t_hit = closest;
+    return any;
+}
+
+// get_sphere_uv, sphere.rs:11-25
+template <typename T> DEV void sphere_uv(V3<T> p, T& u, T& v) {
+    T phi = m_atan2(-p.z, p.x) + PI_T;
+    T theta = m_acos(-p.y);
+    u = phi / (T(2.0) * PI_T);
+    v = theta / PI_T;
+}
+
+// Rebuild the full HitRecord of the winning (object, primitive, t): the same arithmetic the reference runs
+// eagerly inside every `hit`, run once.  Per-lane gathers: lanes may hold different objects.
+template <typename T, uint32_t FEATS>
+DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bool want_uv, Rec<T>& rec) {
+    const DObject ob = P.objects[id.obj];
+    rec.t = t; rec.u = T(0); rec.v = T(0);
+    if ((FEATS & F_MEDIUM) && id.prim == PRIM_MEDIUM) {                               // medium.rs:45-55
+        rec.p = ray_at(ray, t);
+        rec.n = mk<T>(T(1.0), T(0), T(0));
+        rec.front = false;
+        rec.mat = P.media[ob.medium].mat;
+        return;
+    }
+    RayT<T> r = ray;
+    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(P.ops[ob.first_op + k], r);
+    const uint32_t kind = id.prim >> 28, idx = id.prim & 0x0FFFFFFFu;
+    if (kind == G_RECT) {                                                             // rect.rs:61-79
+        const DRect<T> rc = P.rects[idx];
+        uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
+        if ((FEATS & F_TEXTURES) && want_uv) {
+            T a = get(r.o, ai) + t * get(r.d, ai);
+            T b = get(r.o, bi) + t * get(r.d, bi);
+            rec.u = (a - rc.a0) / (rc.a1 - rc.a0);
+            rec.v = (b - rc.b0) / (rc.b1 - rc.b0);
+        }
+        rec.p = ray_at(r, t);
+        V3<T> normal = mk<T>(ki == 0u ? T(1.0) : T(0), ki == 1u ? T(1.0) : T(0), ki == 2u ? T(1.0) : T(0));
+        set_face_normal(rec, r.d, normal);
+        rec.mat = rc.mat;
+    } else if ((FEATS & F_SPHERES) && (kind == G_SPHERE || kind == G_MSPHERE)) {      // sphere.rs:76-94, :170-188
+        V3<T> center; T radius;
+        if (kind == G_SPHERE) { const DSphere<T> s = P.spheres[idx]; center = ld3(s.c); radius = s.r; rec.mat = s.mat; }
+        else { const DMSphere<T> s = P.mspheres[idx]; center = msphere_center(s, r.tm); radius = s.r; rec.mat = s.mat; }
+        rec.p = ray_at(r, t);
+        V3<T> outward = (rec.p - center) / radius;
+        set_face_normal(rec, r.d, outward);
+        if ((FEATS & F_TEXTURES) && want_uv) sphere_uv(outward, rec.u, rec.v);
+    } else if ((FEATS & F_TRIS) && kind == G_TRI) {                                   // tri.rs:42-56
+        const DTri<T> tr = P.tris[idx];
+        V3<T> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
+        if ((FEATS & F_TEXTURES) && want_uv) {
+            V3<T> s = r.o - ld3(tr.v0);
+            V3<T> s1 = cross(r.d, e2);
+            V3<T> s2 = cross(s, e1);
+            T s1_e1 = dot(s1, e1);
+            rec.u = dot(s1, s) / s1_e1;
+            rec.v = dot(s2, r.d) / s1_e1;
+        }
+        rec.p = ray_at(r, t);
+        V3<T> normal = normalized(cross(e1, e2));
+        set_face_normal(rec, r.d, normal);
+        rec.mat = tr.mat;
+    }
+    // unwind the wrapper chain innermost -> outermost
+    for (int k = (int)ob.n_ops - 1; k >= 0; k--) {
+        const DOp<T> op = P.ops[ob.first_op + (uint32_t)k];
+        if (op.kind == OP_TRANSLATE) {
+            rec.p = rec.p + mk<T>(op.x, op.y, op.z);                                  // translate.rs:26
+        } else if (op.kind == OP_ROTATE) {                                            // rotate.rs:90-104
+            RayT<T> rr = ray;                                                         // the ray this Rotate handed to its child
+            for (int q = 0; q <= k; q++) op_fwd(P.ops[ob.first_op + (uint32_t)q], rr);
+            rot_back(op.axis, op.x, op.y, rec.p);
+            V3<T> nw = rec.n;
+            rot_back(op.axis, op.x, op.y, nw);
+            set_face_normal(rec, rr.d, nw);                                           // object-space ray vs world-space normal, as the reference does
+        } else {
+            rec.front = !rec.front;                                                   // FlipNormal, hit.rs:113-119
+        }
+    }
+}
+
+// ------------------------------------------------------------------ textures (texture.rs, perlin.rs)
+DEV uint32_t sat_index(double x) { return x > 0.0 ? (x >= 18446744073709551616.0 ? 0xFFFFFFFFu : (uint32_t)((unsigned long long)x & 0xFFFFFFFFull)) : 0u; }   // low 32 bits of `x as usize`
+DEV uint32_t sat_index(float x) { return x > 0.0f ? (x >= 18446744073709551616.0f ? 0xFFFFFFFFu : (uint32_t)((unsigned long long)x & 0xFFFFFFFFull)) : 0u; }
+DEV unsigned long long sat_u64(double x) { return x > 0.0 ? (x >= 18446744073709551616.0 ? ~0ull : (unsigned long long)x) : 0ull; }
+DEV unsigned long long sat_u64(float x) { return x > 0.0f ? (x >= 18446744073709551616.0f ? ~0ull : (unsigned long long)x) : 0ull; }
+
+template <typename T> DEV T perlin_noise(const DPerlin<T>& pn, V3<T> p, T scale) {    // perlin.rs:77-109 + perlin_interp :39-56
+    T fx = m_floor(scale * p.x), fy = m_floor(scale * p.y), fz = m_floor(scale * p.z);
+    T u = scale * p.x - fx, v = scale * p.y - fy, w = scale * p.z - fz;
+    u = u * u * (T(3.0) - T(2.0) * u);
+    v = v * v * (T(3.0) - T(2.0) * v);
+    w = w * w * (T(3.0) - T(2.0) * w);
+    uint32_t i = sat_index(fx), j = sat_index(fy), k = sat_index(fz);
+    T uu = u * u * (T(3.0) - T(2.0) * u);
+    T vv = v * v * (T(3.0) - T(2.0) * v);
+    T ww = w * w * (T(3.0) - T(2.0) * w);
+    T accum = T(0);
+#pragma unroll
+    for (uint32_t di = 0; di < 2; di++)
+#pragma unroll
+        for (uint32_t dj = 0; dj < 2; dj++)
+#pragma unroll
+            for (uint32_t dk = 0; dk < 2; dk++) {
+                uint32_t h = (uint32_t)pn.perm_x[(i + di) & 255u] ^ (uint32_t)pn.perm_y[(j + dj) & 255u] ^ (uint32_t)pn.perm_z[(k + dk) & 255u];
+                V3<T> c = ld3(&pn.rd_vec[h * 3u]);
+                V3<T> weight = mk<T>(u - T(di), v - T(dj), w - T(dk));
+                T fu = di ? uu : (T(1.0) - uu), fv = dj ? vv : (T(1.0) - vv), fw = dk ? ww : (T(1.0) - ww);
+                accum += fu * fv * fw * dot(c, weight);
+            }
+    return accum;
+}
+template <typename T> DEV T perlin_turb(const DPerlin<T>& pn, V3<T> p, T scale) {     // perlin.rs:111-120, depth 7 (texture.rs:77)
+    T accum = T(0);
+    V3<T> temp_p = p;
+    T weight = T(1.0);
+    for (int d = 0; d < 7; d++) {
+        accum += weight * perlin_noise(pn, temp_p, scale);
+        weight *= T(0.5);
+        temp_p = temp_p * T(2.0);
+    }
+    return m_abs(accum);
+}
+template <typename T> DEV T clamp_(T x, T lo, T hi) { return x < lo ? lo : (x > hi ? hi : x); }   // f64::clamp (NaN stays NaN)
+
+template <typename T, uint32_t FEATS>
+DEV V3<T> tex_eval(const KParams<T>& P, uint32_t id, T u, T v, V3<T> p) {             // Texture::mapping, texture.rs:5-7
+    for (;;) {
+        const DTexture<T> tx = P.textures[id];
+        if (!(FEATS & F_TEXTURES) || tx.kind == T_CONSTANT) return ld3(tx.color);     // texture.rs:23-27
+        if (tx.kind == T_CHECK) {                                                     // texture.rs:45-54
+            T sines = m_sin(T(10.0) * p.x) * m_sin(T(10.0) * p.y) * m_sin(T(10.0) * p.z);
+            id = (sines < T(0)) ? tx.a : tx.b;
+            continue;
+        }
+        if (tx.kind == T_NOISE) {                                                     // texture.rs:71-79
+            T s = T(0.5) * (T(1.0) + m_sin(tx.scale * p.z + T(10.0) * perlin_turb(P.perlins[tx.a], p, tx.scale)));
+            return mk<T>(T(1.0) * s, T(1.0) * s, T(1.0) * s);
+        }
+        // ImageTexture, texture.rs:99-120
+        unsigned long long w = tx.b, h = tx.c;
+        unsigned long long i = sat_u64(clamp_(u, T(0), T(1.0)) * T(w));
+        unsigned long long j = sat_u64(clamp_(T(1.0) - v, T(0), T(1.0)) * T(h));
+        if (i > w - 1) i = w - 1;
+        if (j > h - 1) j = h - 1;
+        const uint8_t* px = P.image_bytes + tx.a + 3ull * i + 3ull * w * j;
+        return mk<T>(T(px[0]) / T(255.0), T(px[1]) / T(255.0), T(px[2]) / T(255.0));
+    }
+}
+
+// ------------------------------------------------------------------ ONB / PDFs / lights (onb.rs, pdf.rs, hit.rs:90-96)
+template <typename T> struct Onb { V3<T> u, v, w; };
+template <typename T> DEV Onb<T> onb_from_w(V3<T> n) {                               // onb.rs:8-20
+    Onb<T> o;
+    o.w = normalized(n);
+    V3<T> a = (m_abs(o.w.x) > T(0.9)) ? mk<T>(T(0), T(1.0), T(0)) : mk<T>(T(1.0), T(0), T(0));
+    o.v = normalized(cross(o.w, a));
+    o.u = cross(o.w, o.v);
+    return o;
+}
+template <typename T> DEV V3<T> onb_local(const Onb<T>& o, V3<T> a) { return a.x * o.u + a.y * o.v + a.z * o.w; }   // onb.rs:34-36
+
+template <typename T> DEV V3<T> random_cosine_direction(Rng& rng) {                   // pdf.rs:8-18
+    T r1 = rng_u01(rng, T(0));
+    T r2 = rng_u01(rng, T(0));
+    T z = rsqrt_(T(1.0) - r2);
+    T phi = T(2.0) * PI_T * r1;
+    T x = m_cos(phi) * rsqrt_(r2);
+    T y = m_sin(phi) * rsqrt_(r2);
+    return mk<T>(x, y, z);
+}
+template <typename T> DEV V3<T> random_in_unit_sphere(Rng& rng) {                     // vec.rs:78-85
+    for (;;) {
+        T a = rng_range(rng, T(-1.0), T(1.0)), b = rng_range(rng, T(-1.0), T(1.0)), c = rng_range(rng, T(-1.0), T(1.0));
+        V3<T> v = mk<T>(a, b, c);
+        if (length(v) < T(1.0)) return v;
+    }
+}
+
+template <typename T, uint32_t FEATS> DEV T light_pdf_value(const KParams<T>& P, DLight L, V3<T> o, V3<T> v) {
+    RayT<T> r; r.o = o; r.d = v; r.tm = T(0);
+    if (L.kind == L_RECT) {                                                           // rect.rs:91-101
+        const DRect<T> rc = P.rects[L.index];
+        T t;
+        if (rect_test(rc, r, T(0.001), Lim<T>::inf(), t)) {
+            uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
+            V3<T> axis = mk<T>(ki == 0u ? T(1.0) : T(0), ki == 1u ? T(1.0) : T(0), ki == 2u ? T(1.0) : T(0));
+            V3<T> n = (dot(v, axis) < T(0)) ? axis : T(-1.0) * axis;
+            T area = (rc.a1 - rc.a0) * (rc.b1 - rc.b0);
+            T distance_squared = (t * t) * sq_of_len(v);
+            T cosine = m_abs(dot(v, n)) / length(v);
+            return (cosine != T(0)) ? distance_squared / (cosine * area) : T(0);
+        }
+        return T(0);
+    }
+    if ((FEATS & F_SPHERES) && L.kind == L_SPHERE) {                                  // sphere.rs:104-112
+        const DSphere<T> s = P.spheres[L.index];
+        T t;
+        if (sphere_test(ld3(s.c), s.r, r, T(0.001), Lim<T>::max(), t)) {
+            T cos_theta_max = rsqrt_(T(1.0) - s.r * s.r / sq_of_len(ld3(s.c) - o));
+            T solid_angle = T(2.0) * PI_T * (T(1.0) - cos_theta_max);
+            return T(1.0) / solid_angle;
+        }
+        return T(0);
+    }
+    return T(0);                                                                      // Hittable::pdf_value default, hit.rs:29
+}
+template <typename T, uint32_t FEATS> DEV V3<T> light_random(const KParams<T>& P, DLight L, V3<T> o, Rng& rng) {
+    if (L.kind == L_RECT) {                                                           // rect.rs:103-111
+        const DRect<T> rc = P.rects[L.index];
+        uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
+        T ra = rng_range(rng, rc.a0, rc.a1);
+        T rb = rng_range(rng, rc.b0, rc.b1);
+        V3<T> pt;
+        pt.x = ki == 0u ? rc.k : (ai == 0u ? ra : rb);
+        pt.y = ki == 1u ? rc.k : (ai == 1u ? ra : rb);
+        pt.z = ki == 2u ? rc.k : rb;
+        return pt - o;
+    }
+    if ((FEATS & F_SPHERES) && L.kind == L_SPHERE) {                                  // sphere.rs:114-119, :27-36
+        const DSphere<T> s = P.spheres[L.index];
+        V3<T> direction = ld3(s.c) - o;
+        T distance_squared = sq_of_len(direction);
+        Onb<T> uvw = onb_from_w(direction);
+        T r1 = rng_u01(rng, T(0));
+        T r2 = rng_u01(rng, T(0));
+        T z = T(1.0) + r2 * (rsqrt_(T(1.0) - s.r * s.r / distance_squared) - T(1.0));
+        T phi = T(2.0) * PI_T * r1;
+        T x = m_cos(phi) * rsqrt_(T(1.0) - z * z);
+        T y = m_sin(phi) * rsqrt_(T(1.0) - z * z);
+        return onb_local(uvw, mk<T>(x, y, z));
+    }
+    return mk<T>(T(1.0), T(0), T(0));                                                 // Hittable::random default, hit.rs:30
+}
+
+// ------------------------------------------------------------------ wave helpers
+DEV uint32_t lane_rank(unsigned long long mask) {   // number of set bits of `mask` below this lane
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+DEV double wave_sum(double x) {                      // fixed butterfly: deterministic for a given set of inputs
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+// Lanes with `need` set hold a partial per-pixel sum (acc) for local pixel acc_px.  All partials of one pixel are
+// combined by a masked butterfly and added to out[] by one lane; the owning wave is the only writer of a pixel.
+DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out, uint32_t lane) {
+    unsigned long long m = __ballot(need);
+    while (m) {
+        uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)acc_px, (int)leader);
+        bool mine = need && acc_px == px;
+        double s0 = wave_sum(mine ? acc[0] : 0.0);
+        double s1 = wave_sum(mine ? acc[1] : 0.0);
+        double s2 = wave_sum(mine ? acc[2] : 0.0);
+        if (lane == leader) {
+            double* o = out + (size_t)px * 3u;
+            o[0] += s0; o[1] += s1; o[2] += s2;
+        }
+        need = need && !mine;
+        m = __ballot(need);
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <typename T, uint32_t FEATS>
+__global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (P.stack_depth * 64u) + lane;
+
+    const uint32_t n_local_px = P.n_local_tiles * P.tile_px;
+    const uint32_t n_px = P.W * P.H;
+    const uint32_t NONE = 0xFFFFFFFFu;
+
+    // wave-uniform queue cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px
+    uint32_t cur_px = 0, end_px = 0, cur_s = 0;
+    bool queue_done = false;
+
+    // per-lane path state
+    bool alive = false;
+    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
+    V3<T> beta = mk<T>(T(0), T(0), T(0));
+    uint32_t depth_left = 0, path_px = 0, path_s = 0;
+    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    // per-lane accumulator for one local pixel
+    uint32_t acc_px = NONE;
+    double acc[3] = {0.0, 0.0, 0.0};
+    uint32_t n_nonfinite = 0;
+    unsigned long long n_iters = 0, n_active = 0;
+
+    for (;;) {
+        // ---- hand the next samples to lanes whose path has ended
+        bool got_new = false;
+        uint32_t new_px = 0, new_s = 0;
+        for (;;) {
+            unsigned long long want = __ballot(!alive && !got_new);
+            if (want == 0) break;
+            if (cur_px == end_px) {
+                if (queue_done) break;
+                uint32_t c = 0;
+                if (lane == 0) c = atomicAdd(P.queue, 1u);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                if (c >= P.n_chunks) { queue_done = true; break; }
+                cur_px = c * P.chunk_px;
+                end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
+                cur_s = 0;
+            }
+            uint32_t avail = P.spp - cur_s;
+            uint32_t n_want = (uint32_t)__popcll(want);
+            uint32_t take = n_want < avail ? n_want : avail;
+            uint32_t rank = lane_rank(want);
+            if (!alive && !got_new && rank < take) { got_new = true; new_px = cur_px; new_s = cur_s + rank; }
+            cur_s += take;
+            if (cur_s == P.spp) { cur_px++; cur_s = 0; }
+        }
+        if (__ballot(alive || got_new) == 0) break;     // queue empty and every path finished
+
+        // ---- lanes moving on to another pixel hand in their partial sum
+        flush_acc(got_new && acc_px != NONE && acc_px != new_px, acc_px, acc, P.out, lane);
+
+        if (got_new) {
+            if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
+            path_px = new_px; path_s = new_s;
+            // local pixel -> global output-order pixel (tile t = rank + q * world)
+            uint32_t q = new_px / P.tile_px, kk = new_px - q * P.tile_px;
+            uint32_t gp = (P.rank + q * P.world) * P.tile_px + kk;
+            if (gp < n_px) {
+                uint32_t row = gp / P.W, i = gp - row * P.W, j = P.H - 1u - row;       // row 0 is j = H-1, main.rs:772
+                rng = rng_for_path(P.seed, gp, new_s);
+                // main.rs:813-820
+                T random_u = rng_u01(rng, T(0));
+                T random_v = rng_u01(rng, T(0));
+                T u = (T(i) + random_u) / T(P.W - 1u);
+                T v = (T(j) + random_v) / T(P.H - 1u);
+                // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
+                T da, db;
+                for (;;) {
+                    da = rng_range(rng, T(-1.0), T(1.0));
+                    db = rng_range(rng, T(-1.0), T(1.0));
+                    V3<T> pd = mk<T>(da, db, T(0));
+                    if (length(pd) < T(1.0)) break;
+                }
+                V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
+                V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
+                T time = P.cam.time0 + rng_u01(rng, T(0)) * (P.cam.time1 - P.cam.time0);
+                ray.o = ld3(P.cam.origin) + offset;
+                ray.d = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
+                ray.tm = time;
+                beta = mk<T>(T(1.0), T(1.0), T(1.0));
+                depth_left = P.max_depth;
+                alive = true;
+            }
+        }
+
+        n_iters++;
+        if (alive) n_active++;
+
+        // ---- one level of ray_color (main.rs:41-120) for every live lane
+        if (alive) {
+            bool done = false;
+            V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
+            if (depth_left == 0) {
+                done = true;                            // main.rs:42-45
+            } else {
+                T t_hit; HitId id; id.obj = 0; id.prim = 0;
+                if (!world_hit<T, FEATS>(P, ray, T(0.00001), rng, t_hit, id, stack)) {       // main.rs:48
+                    e = ld3(P.background); done = true;                                     // main.rs:118
+                } else {
+                    // material of the hit decides whether (u,v) are needed at all
+                    Rec<T> rec;
+                    finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
+                    const DMaterial<T> mt = P.materials[rec.mat];
+                    if (mt.kind == M_LAMBERTIAN) {                                          // mat.rs:225-249, main.rs:92-98
+                        V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+                        Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::cosine_pdf, pdf.rs:81-85
+                        V3<T> dir; T pdf_value;
+                        if (P.n_lights == 0u) {                                             // stated deviation D2 (reference panics)
+                            dir = onb_local(uvw, random_cosine_direction<T>(rng));
+                            T cosine = dot(normalized(dir), uvw.w);
+                            pdf_value = (cosine > T(0)) ? cosine / PI_T : T(0);
+                        } else {
+                            if (rng_bool(rng)) {                                            // pdf.rs:167-173
+                                uint32_t li = rng_index(rng, P.n_lights);                   // hit.rs:94-96
+                                dir = light_random<T, FEATS>(P, P.lights[li], rec.p, rng);
+                            } else {
+                                dir = onb_local(uvw, random_cosine_direction<T>(rng));
+                            }
+                            T lsum = T(0);                                                  // hit.rs:90-92
+                            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, P.lights[li], rec.p, dir);
+                            T lpdf = lsum / T(P.n_lights);
+                            T cosine = dot(normalized(dir), uvw.w);                         // pdf.rs:131-139
+                            T cpdf = (cosine > T(0)) ? cosine / PI_T : T(0);
+                            pdf_value = T(0.5) * lpdf + T(0.5) * cpdf;                      // pdf.rs:143-145
+                        }
+                        T sc = m_max(dot(rec.n, normalized(dir)), T(0)) / PI_T;             // scattering_pdf, mat.rs:246-249
+                        beta = (beta * (attenuation * sc)) / pdf_value;                     // main.rs:97 (emitted is the literal zero here)
+                        ray.o = rec.p; ray.d = dir;                                         // time unchanged
+                    } else if (mt.kind == M_METAL) {                                        // mat.rs:280-293
+                        V3<T> dn = ray.d + ((-dot(ray.d, rec.n)) * T(2.0) * rec.n);         // reflect, vec.rs:112-114
+                        V3<T> reflected = normalized(dn);
+                        V3<T> fz = random_in_unit_sphere<T>(rng);
+                        V3<T> sd = reflected + mt.param * fz;
+                        if (dot(sd, rec.n) > T(0)) { beta = ld3(mt.albedo) * beta; ray.o = rec.p; ray.d = sd; }   // main.rs:89-91
+                        else done = true;                                                   // None -> emitted = 0, main.rs:108-110
+                    } else if ((FEATS & F_DIELECTRIC) && mt.kind == M_DIELECTRIC) {         // mat.rs:343-374
+                        T refraction_ratio = rec.front ? T(1.0) / mt.param : mt.param;
+                        V3<T> unit_direction = normalized(ray.d);
+                        T cos_theta = m_min(dot(T(-1.0) * unit_direction, rec.n), T(1.0));
+                        T sin_theta = rsqrt_(T(1.0) - cos_theta * cos_theta);
+                        bool cannot_refract = refraction_ratio * sin_theta > T(1.0);
+                        T q = (T(1.0) - refraction_ratio) / (T(1.0) + refraction_ratio);    // reflectance, mat.rs:309-313
+                        T r0 = q * q;
+                        T m1 = T(1.0) - cos_theta, m2 = m1 * m1;
+                        T refl = r0 + (T(1.0) - r0) * (m1 * (m2 * m2));
+                        bool will_reflect = rng_u01(rng, T(0)) < refl;
+                        V3<T> direction;
+                        if (cannot_refract || will_reflect) {
+                            direction = unit_direction + ((-dot(unit_direction, rec.n)) * T(2.0) * rec.n);
+                        } else {                                                            // refract, vec.rs:116-121
+                            T ct = m_min(dot(T(-1.0) * unit_direction, rec.n), T(1.0));
+                            V3<T> r_out_perp = refraction_ratio * (unit_direction + ct * rec.n);
+                            T l = length(r_out_perp);
+                            V3<T> r_out_para = (T(-1.0) * rsqrt_(m_abs(T(1.0) - l * l))) * rec.n;
+                            direction = r_out_perp + r_out_para;
+                        }
+                        ray.o = rec.p; ray.d = direction;                                   // attenuation (1,1,1): beta unchanged
+                    } else if (mt.kind == M_DIFFUSE_LIGHT) {                                // mat.rs:395-401; no scatter -> main.rs:108-110
+                        if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+                        done = true;
+                    } else {                                                                // Isotropic: no scatter_mc_method (mat.rs:417-422) -> absorbs
+                        done = true;
+                    }
+                    if (!done) {
+                        depth_left--;
+                        if (depth_left == 0) done = true;                                   // the child call returns 0 at main.rs:42-45
+                        if ((P.flags & 2u) && beta.x == T(0) && beta.y == T(0) && beta.z == T(0)) done = true;   // RT_STOP_ON_ZERO (opt-in)
+                    }
+                }
+            }
+            if (done) {
+                V3<T> L = beta * e;
+                double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
+                acc[0] += l0; acc[1] += l1; acc[2] += l2;
+                if (!(l0 - l0 == 0.0 && l1 - l1 == 0.0 && l2 - l2 == 0.0)) n_nonfinite++;
+                if (P.samples_out) {
+                    double* so = P.samples_out + ((size_t)path_px * P.spp + path_s) * 3u;
+                    so[0] = l0; so[1] = l1; so[2] = l2;
+                }
+                alive = false;
+            }
+        }
+    }
+    // ---- the queue is empty: hand in what is left
+    flush_acc(acc_px != NONE, acc_px, acc, P.out, lane);
+    if (P.stats) {
+        if (n_nonfinite) atomicAdd(&P.stats[0], (unsigned long long)n_nonfinite);
+        unsigned long long a = n_active;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+        if (lane == 0) { atomicAdd(&P.stats[1], n_iters); atomicAdd(&P.stats[2], a); }
+    }
+}
+
+// ------------------------------------------------------------------ launch
+template <typename T, uint32_t FEATS>
+static hipError_t launch_one(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
+    hipLaunchKernelGGL((pathtrace_kernel<T, FEATS>), dim3(n_blocks), dim3(256), shmem, stream, P);
+    return hipGetLastError();
+}
+template <typename T, uint32_t FEATS>
+static int occupancy_one(size_t shmem) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pathtrace_kernel<T, FEATS>, 256, shmem) != hipSuccess) return 0;
+    return nb;
+}
+
+// Two instantiations per arithmetic type: the lean one (rects + instances + Lambertian/Metal/DiffuseLight —
+// everything the Cornell box needs) and the full one.
+static const uint32_t FEATS_LEAN = 0u;
+
+template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
+    if ((scene_feats & ~FEATS_LEAN) == 0u) return launch_one<T, FEATS_LEAN>(P, n_blocks, shmem, stream);
+    return launch_one<T, F_ALL>(P, n_blocks, shmem, stream);
+}
+template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, size_t shmem) {
+    if ((scene_feats & ~FEATS_LEAN) == 0u) return occupancy_one<T, FEATS_LEAN>(shmem);
+    return occupancy_one<T, F_ALL>(shmem);
+}
+
+template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);
+template hipError_t launch_pathtrace<float>(const KParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
+template int pathtrace_blocks_per_cu<double>(uint32_t, size_t);
+template int pathtrace_blocks_per_cu<float>(uint32_t, size_t);
+
+} // namespace rt

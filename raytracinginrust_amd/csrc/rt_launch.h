@@ -1,0 +1,11 @@
+// csrc/rt_launch.h — interface between the host library (rt_host.cpp) and the kernels (rt_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "rt_ir.h"
+
+namespace rt {
+// Launch the persistent path-tracing kernel: n_blocks blocks of 256 threads, `shmem` bytes of LDS for BVH stacks.
+template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
+// Resident blocks per CU for the instantiation that serves `scene_feats`.
+template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, size_t shmem);
+}

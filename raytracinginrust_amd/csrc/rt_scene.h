@@ -1,0 +1,74 @@
+// csrc/rt_scene.h — host-side scene: the builder tree behind the C-ABI handles, and its flattened form.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "rt_ir.h"
+#include "rt_rng.h"
+
+namespace rt {
+
+// One node per reference constructor call (Sphere::new, Translate::new, ...).
+struct HNode {
+    enum Kind { SPHERE, MSPHERE, RECT, CUBE, TRI, LIST, FLIP, TRANSLATE, ROTATE, MEDIUM, BVH } kind;
+    double v[12] = {0};        // SPHERE: c, r | MSPHERE: c0, c1, t0, t1, r | RECT: a0,a1,b0,b1,k | CUBE: min,max | TRI: 9 | TRANSLATE: offset | ROTATE: angle | MEDIUM: density
+    int plane_or_axis = 0;     // RECT: plane; ROTATE: axis
+    int mat = -1;              // prims; MEDIUM: texture id
+    int child = -1;            // wrappers / MEDIUM boundary
+    std::vector<int> items;    // LIST items, BVH children
+};
+
+struct HPerlin { double rd_vec[256 * 3]; uint8_t perm[3][256]; };
+
+struct HostFlat {             // canonical f64 flattening
+    std::vector<DObject> objects;
+    std::vector<DOp<double>> ops;
+    std::vector<DRect<double>> rects;
+    std::vector<DSphere<double>> spheres;
+    std::vector<DMSphere<double>> mspheres;
+    std::vector<DTri<double>> tris;
+    std::vector<DBvhNode<double>> bvh;
+    std::vector<DMaterial<double>> materials;
+    std::vector<DTexture<double>> textures;
+    std::vector<DMedium<double>> media;
+    std::vector<DLight> lights;
+    uint32_t feats = 0;
+    uint32_t bvh_depth = 0;
+};
+
+template <typename T> struct DeviceScene {   // device copies of HostFlat for one arithmetic type
+    bool valid = false;
+    void* objects = nullptr; void* ops = nullptr; void* rects = nullptr; void* spheres = nullptr; void* mspheres = nullptr;
+    void* tris = nullptr; void* bvh = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
+    void* lights = nullptr; void* perlins = nullptr; void* image = nullptr;
+};
+
+struct Scene {
+    std::vector<HNode> nodes;
+    std::vector<DMaterial<double>> materials;
+    std::vector<DTexture<double>> textures;
+    std::vector<HPerlin> perlins;
+    std::vector<uint8_t> image_bytes;
+    int world = -1;
+    std::vector<int> lights;
+    std::string error;
+
+    bool flat_valid = false;
+    HostFlat flat;
+    DeviceScene<double> dev64;
+    DeviceScene<float> dev32;
+    // launch scratch (device): queue counter, stats, events
+    void* d_queue = nullptr; void* d_stats = nullptr;
+    void* ev_start = nullptr; void* ev_stop = nullptr; bool ev_recorded = false;
+    unsigned long long last_stats[4] = {0, 0, 0, 0};
+
+    void invalidate() { flat_valid = false; }
+};
+
+// rt_flatten.cpp
+bool flatten_scene(Scene& s);
+// camera (src/camera.rs:19-49)
+struct rt_camera_args { double lookfrom[3], lookat[3], vup[3], vfov, aspect, aperture, focus_dist, time0, time1; };
+void camera_new(const rt_camera_args& a, DCamera<double>& out);
+
+} // namespace rt

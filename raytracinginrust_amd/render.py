@@ -1,0 +1,113 @@
+"""Host-side mirror of the reference's render loop (src/main.rs:767-835) over the C-ABI.
+
+`render()` is the single call that replaces the `for j / for i / into_par_iter().map().sum()` nest;
+`render_tiles_device()` is the tile-sharded form used one-process-per-GPU (see dist.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .api import CameraParams, SceneBuilder
+
+RT_F64, RT_F32, RT_STOP_ON_ZERO = 0, 1, 2
+FLATTEN_COUNT_NAMES = ("objects", "ops", "rects", "spheres", "moving_spheres", "triangles", "bvh_nodes",
+                       "materials", "textures", "lights", "media", "perlins")
+
+
+class RenderError(RuntimeError):
+    pass
+
+
+def _err(be) -> str:
+    return be.lib.rt_last_error().decode()
+
+
+def device_count() -> int:
+    return _lib.load().lib.rt_device_count()
+
+
+def flatten(b: SceneBuilder) -> dict:
+    """Flatten the Hittable tree into the device scene (host only) and return the table sizes."""
+    be = _lib.load()
+    counts = (C.c_uint32 * 12)()
+    if be.lib.rt_scene_flatten(b.h, counts) != 0:
+        raise RenderError(_err(be))
+    return dict(zip(FLATTEN_COUNT_NAMES, [int(x) for x in counts]))
+
+
+def render(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int,
+           seed: int = 0x5EED, flags: int = RT_F64, want_samples: bool = False):
+    """Per-pixel sums of ray_color over `spp` samples, shape (H, W, 3) f64, row 0 = top (what `.sum()`
+    yields at src/main.rs:830, in the order the reference prints pixels).  With want_samples also returns
+    the (H, W, spp, 3) per-sample radiance."""
+    be = _lib.load()
+    out = np.zeros((H, W, 3), dtype=np.float64)
+    bg = (C.c_double * 3)(*[float(x) for x in background])
+    if want_samples:
+        samples = np.zeros((H, W, spp, 3), dtype=np.float64)
+        rc = be.lib.rt_render_samples(b.h, C.byref(cam), bg, W, H, spp, max_depth, seed, flags, out.ctypes.data, samples.ctypes.data)
+    else:
+        samples = None
+        rc = be.lib.rt_render(b.h, C.byref(cam), bg, W, H, spp, max_depth, seed, flags, out.ctypes.data)
+    if rc != 0:
+        raise RenderError(_err(be))
+    return (out, samples) if want_samples else out
+
+
+def local_tiles(W: int, H: int, tile_px: int, rank: int, world: int) -> int:
+    return int(_lib.load().lib.rt_local_tiles(W, H, tile_px, rank, world))
+
+
+def render_tiles_device(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int,
+                        seed: int, flags: int, tile_px: int, rank: int, world: int, d_out_ptr: int, d_out_bytes: int,
+                        stream: int = 0) -> None:
+    """Asynchronously render tiles t ≡ rank (mod world) into device memory at d_out_ptr on `stream`."""
+    be = _lib.load()
+    bg = (C.c_double * 3)(*[float(x) for x in background])
+    rc = be.lib.rt_render_device(b.h, C.byref(cam), bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world,
+                                 C.c_void_p(d_out_ptr), d_out_bytes, C.c_void_p(stream))
+    if rc != 0:
+        raise RenderError(_err(be))
+
+
+def last_kernel_ms(b: SceneBuilder) -> float:
+    be = _lib.load()
+    ms = C.c_float()
+    if be.lib.rt_last_kernel_ms(b.h, C.byref(ms)) != 0:
+        raise RenderError(_err(be))
+    return float(ms.value)
+
+
+def last_stats(b: SceneBuilder) -> dict:
+    be = _lib.load()
+    st = (C.c_ulonglong * 3)()
+    if be.lib.rt_last_stats(b.h, st) != 0:
+        raise RenderError(_err(be))
+    return {"nonfinite_samples": int(st[0]), "wave_iterations": int(st[1]), "live_lane_iterations": int(st[2])}
+
+
+def format_image(rgb_sum: np.ndarray, spp: int) -> np.ndarray:
+    """Vec3::format_color (src/vec.rs:125-131) over a whole frame -> (H, W, 3) uint8-range ints."""
+    be = _lib.load()
+    H, W, _ = rgb_sum.shape
+    out = np.zeros((H, W, 3), dtype=np.uint64)
+    flat = np.ascontiguousarray(rgb_sum, dtype=np.float64).reshape(-1, 3)
+    o = out.reshape(-1, 3)
+    fn = be.fn("format_color")
+    buf = (C.c_uint64 * 3)()
+    for p in range(flat.shape[0]):
+        fn(flat[p].ctypes.data_as(C.POINTER(C.c_double)), spp, buf)
+        o[p, 0], o[p, 1], o[p, 2] = buf[0], buf[1], buf[2]
+    return out
+
+
+def write_ppm(path: str, rgb_sum: np.ndarray, spp: int) -> None:
+    """The reference's P3 emitter (src/main.rs:767-769,832)."""
+    be = _lib.load()
+    H, W, _ = rgb_sum.shape
+    a = np.ascontiguousarray(rgb_sum, dtype=np.float64)
+    if be.lib.rt_write_ppm(path.encode(), a.ctypes.data, W, H, spp) != 0:
+        raise RenderError(_err(be))
