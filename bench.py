@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s of the path-tracing hot path on BASELINE config 2
+(Cornell box 800x800, 1024 spp, depth 50) in f64 (the reference's arithmetic type).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one whole frame: every rank renders its interleaved tiles (one persistent HIP kernel launch per
+rank), then ONE gather (RCCL over xGMI) moves them to rank 0.  The frame is fixed as N grows (strong scaling).
+For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
+Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per launch (SURVEY §8(d) model x samples in
+the launch) / mean kernel duration from HIP events recorded on the launch stream inside the timed region.
+`cpu_baseline` (N = 1 only) times the CPU oracle — a restatement of the reference, not the Rust binary, which
+cannot be built here — on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(w, sample_spp):
+    """CPU restatement of the reference (oracle/), all host threads, on the workload's own pixel grid at
+    `sample_spp` samples per pixel.  Also returns the oracle's algorithmic bytes/sample for this workload."""
+    from oracle import orc
+    from raytracinginrust_amd import workloads
+    be = orc.load()
+    b, cam, bg = workloads.build(w, be)
+    threads = orc.hardware_threads()
+    t = time.perf_counter()
+    _, cnt = orc.render(b, cam, bg, w.W, w.H, sample_spp, w.max_depth, want_counters=True, nthreads=threads, mode=0)
+    dt = time.perf_counter() - t
+    n = w.W * w.H * sample_spp
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
+            "sample": f"{w.scene} {w.W}x{w.H} at {sample_spp} spp ({n / 1e6:.1f} Msamples, {dt:.1f} s wall, "
+                      f"oracle f64, threads over rows)"}, orc.algorithmic_bytes_per_sample(cnt, sample_spp)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C2")
+    ap.add_argument("--tile-px", type=int, default=64)
+    ap.add_argument("--f32", action="store_true", help="throughput variant (not the headline: reduced precision)")
+    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracinginrust_amd import _lib, dist as D, render as R, workloads
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    be = _lib.load()            # after `import torch`: one HIP runtime in the process
+    w = workloads.WORKLOADS[args.workload]
+    earth = None
+    if w.scene == "final":
+        from PIL import Image
+        from raytracinginrust_amd import scenes
+        im = Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")
+        earth = (im.tobytes(), im.size[0], im.size[1])
+    b, cam, bg = workloads.build(w, be, earth)
+    flags = R.RT_F32 if args.f32 else R.RT_F64
+    tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.render_frame(dst=0)
+    sync()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame = tr.render_frame(dst=0)
+        kernel_ms.append(R.last_kernel_ms(b))      # HIP events on the launch stream; waits for this rank's kernel only
+    sync()
+    elapsed = time.perf_counter() - t0
+    stats = R.last_stats(b)
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
+        mean_radiance = float(torch.nan_to_num(frame).mean().item()) / w.spp
+        value = w.samples * args.steps / elapsed / 1e6
+        cpu, bps = None, workloads.BYTES_PER_SAMPLE.get(w.key)
+        if world == 1 and args.cpu_spp > 0 and not args.f32:
+            cpu, bps = cpu_baseline(w, args.cpu_spp)
+        k_ms = sum(kernel_ms) / len(kernel_ms)
+        n_px = w.W * w.H                     # real (unpadded) pixels rank 0's launch owns
+        local_px = sum(max(0, min(n_px, (t + 1) * args.tile_px) - t * args.tile_px)
+                       for t in D.local_tile_ids(w.W, w.H, args.tile_px, rank, world) if t * args.tile_px < n_px)
+        local_samples = local_px * w.spp
+        roof = None
+        if bps is not None:
+            achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                    "traffic": None, "kernel": "rt::pathtrace_kernel<double, 0>" if not args.f32 else "rt::pathtrace_kernel<float, 0>",
+                    "kernel_ms": k_ms, "bytes_per_sample": bps,
+                    "note": "algorithmic bytes (event x record-size model, SURVEY 8(d)); the scene is L2/LDS-resident, "
+                            "physical HBM traffic is ~ the framebuffer (see DESIGN.md / profiles/)"}
+        out = {
+            "metric": "Msamples/s (pixels x spp / s)", "value": value, "unit": "Msamples/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32" if args.f32 else "f64", "data": "synthetic",
+            "config": {"workload": f"{w.key}: {w.describe()}", "tile_px": args.tile_px, "seed": "0x5EED",
+                       "parallelism": f"tiles interleaved over {world} GPU(s) + 1 gather"},
+            "roofline": roof, "cpu_baseline": cpu,
+            "lane_utilisation": stats["live_lane_iterations"] / max(1, 64 * stats["wave_iterations"]),
+            "nonfinite_samples_rank0": stats["nonfinite_samples"], "mean_radiance": mean_radiance,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -379,12 +379,17 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     return 0;
 }
 
-int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
-               uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
-               void* d_samples, hipStream_t stream) {
+int check_frame_args(rt_scene* sc, const rt_camera* cam, const double* bg, uint32_t W, uint32_t H, uint32_t spp) {
     if (!sc || !cam || !bg) return set_err("null argument");
     if (W < 2 || H < 2) return set_err("W and H must be >= 2 (u,v divide by W-1 and H-1, src/main.rs:817-818)");
     if (spp == 0) return set_err("samples_per_pixel must be >= 1");
+    return 0;
+}
+
+int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+               uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
+               void* d_samples, hipStream_t stream) {
+    if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
     if (tile_px == 0 || world == 0 || rank >= world) return set_err("bad tile decomposition");
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
@@ -419,6 +424,7 @@ int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {
 int rt_render_samples(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                       uint64_t seed, uint32_t flags, double* rgb_sum_out, double* samples_out) {
     if (!rgb_sum_out) return set_err("null output");
+    if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
     size_t n_px = (size_t)W * H;
     void* d_out = nullptr; void* d_samples = nullptr;
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");

@@ -61,6 +61,11 @@ template <typename T> struct Lim;
 template <> struct Lim<double> { static DEV double max() { return 1.7976931348623157e308; } static DEV double inf() { return __longlong_as_double(0x7FF0000000000000LL); } };
 template <> struct Lim<float> { static DEV float max() { return 3.402823466e38f; } static DEV float inf() { return __uint_as_float(0x7F800000u); } };
 #define PI_T T(3.14159265358979323846264338327950288)
+// t_min of world.hit (main.rs:48).  The reference's 0.00001 is below one f32 ulp at Cornell scale (ulp(555) = 6e-5),
+// so the f32 throughput variant uses the 0.001 the reference's own comment (main.rs:47) names; f64 keeps 0.00001.
+template <typename T> struct TMin;
+template <> struct TMin<double> { static DEV double v() { return 0.00001; } };
+template <> struct TMin<float> { static DEV float v() { return 0.001f; } };
 
 template <typename T> struct RayT { V3<T> o, d; T tm; };
 template <typename T> DEV V3<T> ray_at(const RayT<T>& r, T t) { return r.o + t * r.d; }                             // ray.rs:26-28
@@ -627,7 +632,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
                 done = true;                            // main.rs:42-45
             } else {
                 T t_hit; HitId id; id.obj = 0; id.prim = 0;
-                if (!world_hit<T, FEATS>(P, ray, T(0.00001), rng, t_hit, id, stack)) {       // main.rs:48
+                if (!world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack)) {       // main.rs:48
                     e = ld3(P.background); done = true;                                     // main.rs:118
                 } else {
                     // material of the hit decides whether (u,v) are needed at all

@@ -1,0 +1,78 @@
+"""One process per GPU: image tiles shard across ranks, one gather (RCCL over xGMI) at frame end.
+
+The frame's W*H pixels (output order) are cut into tiles of `tile_px` consecutive pixels; rank r of N
+renders tiles t with t % N == r (interleaved, so expensive image regions spread over all GPUs) into a
+packed device buffer, and a single `torch.distributed.gather` moves the N buffers to rank 0, which
+un-permutes them into the frame.  There is no other data-path collective: pixels are independent and
+the scene (< 2 MB) is replicated.  `torch.distributed` with backend "nccl" is RCCL on ROCm; the same
+code runs over "gloo" with CPU tensors for the multi-process tests.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import render as R
+
+
+def n_tiles(W: int, H: int, tile_px: int) -> int:
+    return (W * H + tile_px - 1) // tile_px
+
+
+def n_local_tiles(W: int, H: int, tile_px: int, world: int) -> int:
+    """Tiles per rank, padded so that it is the same on every rank (a plain gather needs equal counts)."""
+    return (n_tiles(W, H, tile_px) + world - 1) // world
+
+
+def local_tile_ids(W: int, H: int, tile_px: int, rank: int, world: int):
+    """Global tile index of each local slot q (may point past the last real tile: padding)."""
+    return [rank + q * world for q in range(n_local_tiles(W, H, tile_px, world))]
+
+
+def assemble(gathered: torch.Tensor, W: int, H: int, tile_px: int) -> torch.Tensor:
+    """[world, n_local, tile_px, 3] rank-major tile buffers -> (H, W, 3) frame."""
+    world, n_local = gathered.shape[0], gathered.shape[1]
+    frame = gathered.permute(1, 0, 2, 3).reshape(n_local * world * tile_px, 3)
+    return frame[: W * H].reshape(H, W, 3)
+
+
+def gather_frame(local: torch.Tensor, W: int, H: int, tile_px: int, dst: int = 0):
+    """`local`: this rank's [n_local, tile_px, 3] buffer.  Returns the (H, W, 3) frame on `dst`, None elsewhere."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return assemble(local.unsqueeze(0), W, H, tile_px)
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return assemble(torch.stack(bufs, 0), W, H, tile_px)
+
+
+class TileRenderer:
+    """Per-rank render state: the replicated scene and a reusable device buffer for this rank's tiles."""
+
+    def __init__(self, builder, cam, background, W, H, spp, max_depth, seed=0x5EED, flags=R.RT_F64, tile_px=64,
+                 rank=None, world=None, device=None):
+        self.b, self.cam, self.bg = builder, cam, background
+        self.W, self.H, self.spp, self.max_depth, self.seed, self.flags, self.tile_px = W, H, spp, max_depth, seed, flags, tile_px
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.n_local = n_local_tiles(W, H, tile_px, self.world)
+        assert self.n_local == R.local_tiles(W, H, tile_px, self.rank, self.world)
+        self.local = torch.empty((self.n_local, tile_px, 3), dtype=torch.float64, device=self.device)
+
+    def render_local(self) -> torch.Tensor:
+        """Launch the path-tracing kernel for this rank's tiles on torch's current stream (asynchronous)."""
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        R.render_tiles_device(self.b, self.cam, self.bg, self.W, self.H, self.spp, self.max_depth, self.seed, self.flags,
+                              self.tile_px, self.rank, self.world, self.local.data_ptr(),
+                              self.local.numel() * self.local.element_size(), stream)
+        return self.local
+
+    def render_frame(self, dst: int = 0):
+        """One frame: local tiles, then the single gather.  Returns the (H, W, 3) per-pixel sums on `dst`."""
+        local = self.render_local()
+        if self.world == 1:
+            return assemble(local.unsqueeze(0), self.W, self.H, self.tile_px)
+        return gather_frame(local, self.W, self.H, self.tile_px, dst)

@@ -1,0 +1,48 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def obe():
+    """The CPU oracle (test infrastructure) as a builder backend."""
+    from oracle import orc
+    return orc.load()
+
+
+@pytest.fixture(scope="session")
+def pbe():
+    """The product library librt_amd.so; a missing library is an error, never a skip."""
+    from raytracinginrust_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture(scope="session")
+def earth():
+    """Decoded earthmap texels (tests/golden/earthmap_256x128.png) -> (bytes, w, h)."""
+    from PIL import Image
+    from raytracinginrust_amd import scenes
+    im = Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")
+    return im.tobytes(), im.size[0], im.size[1]
+
+
+def build_scene(name, backend, earth=None):
+    from raytracinginrust_amd import scenes
+    if name == "cornell":
+        return scenes.cornell_box(backend)
+    if name == "random":
+        return scenes.random_scene(backend, aspect_ratio=16.0 / 9.0)
+    if name == "final":
+        return scenes.final_scene(backend, *earth)
+    if name == "teapot":
+        return scenes.cornell_test(backend, scenes.asset_path("teapot.obj"), aspect_ratio=16.0 / 9.0)
+    raise KeyError(name)

@@ -1,0 +1,19 @@
+"""Makes the data fixtures under tests/golden/ from the reference's asset files (run once, in the build
+container where /root/reference is mounted; the GPU box only sees the committed outputs).
+
+  teapot.obj            byte copy of /root/reference/teapot.obj (Utah teapot mesh: 530 v, 1024 f) — input data
+                        for BASELINE config 4 (tri.rs / mesh.rs path)
+  earthmap_256x128.png  /root/reference/earthmap.jpg (1024x512 baseline JPEG) decoded with Pillow and box-
+                        downsampled 4x, stored losslessly — input texels for the ImageTexture path.  (The
+                        reference decodes with the `image` crate; decoders may differ by +-1 LSB, SURVEY §8(c),
+                        so the decoded texels, not the JPEG, are the fixture.)
+"""
+import os, shutil
+from PIL import Image
+here = os.path.dirname(os.path.abspath(__file__))
+shutil.copyfile("/root/reference/teapot.obj", os.path.join(here, "teapot.obj"))
+im = Image.open("/root/reference/earthmap.jpg").convert("RGB")
+assert im.size == (1024, 512)
+im.resize((256, 128), Image.BOX).save(os.path.join(here, "earthmap_256x128.png"), optimize=True)
+print("ok")
+

@@ -1,0 +1,150 @@
+"""Host-side logic of the product library (no GPU needed): the C-ABI loads and exports what include/rt_amd.h
+declares, the seeded stream / Camera::new / format_color / PPM emitter agree with the oracle bit for bit,
+scenes flatten to the expected device tables, and error paths return errors instead of panicking."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, build_scene
+from oracle import orc
+from raytracinginrust_amd import _lib, render as R, scenes
+from raytracinginrust_amd.api import Axis, Camera, Plane, Rng, SceneBuilder, SceneError, camera_fields, format_color
+
+
+def test_library_exports_every_declared_symbol(pbe):
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) > 40
+    missing = [n for n in names if not hasattr(pbe.lib, n)]
+    assert missing == []
+
+
+def test_rng_streams_match_oracle_bitwise(obe, pbe):
+    for seed, stream in [(0x5EED, 0), (0, 1), (2 ** 64 - 1, 16), (123456789, 7)]:
+        a, b = Rng(obe, seed, stream), Rng(pbe, seed, stream)
+        for k in range(300):
+            m = k % 5
+            if m == 0:
+                assert a.gen_f64() == b.gen_f64()
+            elif m == 1:
+                assert a.gen_range(-1.0, 1.0) == b.gen_range(-1.0, 1.0)
+            elif m == 2:
+                assert a.gen_bool() == b.gen_bool()
+            elif m == 3:
+                assert a.gen_index(k + 1) == b.gen_index(k + 1)
+            else:
+                assert a.gen_range(213.0, 343.0) == b.gen_range(213.0, 343.0)
+    sa, sb = (C.c_uint32 * 4)(), (C.c_uint32 * 4)()
+    for pix, s in [(0, 0), (1, 0), (0, 1), (639999, 1023), (8294399, 8191), (2 ** 31 - 1, 2 ** 32 - 1)]:
+        obe.fn("rng_path")(0x5EED, pix, s, sa)
+        pbe.fn("rng_path")(0x5EED, pix, s, sb)
+        assert list(sa) == list(sb)
+
+
+CAMERAS = [
+    ((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), 20.0, 16.0 / 9.0, 0.1),          # main.rs:630-635
+    ((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), 40.0, 1.0, 0.05),      # main.rs:700-705
+    ((199.0, 439.0, -200.0), (278.0, 375.0, 258.0), 30.0, 16.0 / 9.0, 0.01),   # main.rs:728-733
+    ((478.0, 278.0, -600.0), (278.0, 278.0, 0.0), 40.0, 1.0, 0.01),      # main.rs:742-747
+]
+
+
+@pytest.mark.parametrize("lf,la,vfov,aspect,ap", CAMERAS)
+def test_camera_new_matches_oracle_bitwise(obe, pbe, lf, la, vfov, aspect, ap):
+    cam = Camera(lf, la, (0.0, 1.0, 0.0), vfov, aspect, ap, 10.0, 0.0, 1.0)
+    assert camera_fields(obe, cam) == camera_fields(pbe, cam)
+
+
+def test_format_color_matches_oracle(obe, pbe):
+    rs = np.random.RandomState(0)
+    vals = list(rs.uniform(0, 40, size=(200, 3))) + [
+        (float("nan"), float("inf"), -1.0), (0.0, -0.0, 1e-320), (16.0, 15.999, 16.001), (1e300, 1e-300, 3.99)]
+    for v in vals:
+        for spp in (1, 16, 1024):
+            assert format_color(obe, v, spp) == format_color(pbe, v, spp)
+    assert format_color(pbe, (float("nan"), float("inf"), 4.0), 16) == (0, 255, 128)
+
+
+def test_write_ppm_layout(tmp_path, pbe):
+    """src/main.rs:767-769,832: P3 header, one `r g b` line per pixel, rows top to bottom"""
+    img = np.zeros((2, 3, 3))
+    img[0, 0] = (16.0, 0.0, 0.0)
+    img[1, 2] = (0.0, 4.0, float("nan"))
+    p = str(tmp_path / "o.ppm")
+    R.write_ppm(p, img, 16)
+    lines = open(p).read().split("\n")
+    assert lines[:3] == ["P3", "3 2", "255"]
+    assert lines[3] == "255 0 0" and lines[3 + 5] == "0 128 0" and len([l for l in lines if l]) == 3 + 6
+
+
+def test_flatten_tables(pbe, earth):
+    c = R.flatten(build_scene("cornell", pbe)[0])
+    # 6 wall/light rects + 2 x 6 cube faces; runs of bare rects merge into one typed range each:
+    # [green, red] [FlipNormal(light)] [floor, ceiling, back] [box] [box]
+    assert (c["objects"], c["ops"], c["rects"], c["lights"], c["bvh_nodes"]) == (5, 5, 18, 1, 0)
+    r = R.flatten(build_scene("random", pbe)[0])
+    assert r["spheres"] + r["moving_spheres"] == 533 and r["bvh_nodes"] == 2 * 533 - 1 and r["lights"] == 0
+    f = R.flatten(build_scene("final", pbe, earth)[0])
+    assert f["rects"] == 400 * 6 + 1 and f["spheres"] == 1000 + 6 - 1 + 1 and f["moving_spheres"] == 1
+    assert f["bvh_nodes"] == (2 * 400 - 1) + (2 * 1000 - 1) and f["media"] == 2 and f["perlins"] == 1 and f["objects"] == 11 - 3
+    t = R.flatten(build_scene("teapot", pbe)[0])
+    assert t["triangles"] == 1024 and t["bvh_nodes"] == 2047 and t["rects"] == 6
+
+
+def test_obj_loader_teapot():
+    pos, idx = scenes.load_obj(scenes.asset_path("teapot.obj"), (0.0, 0.0, 0.0), 1.0)
+    assert len(pos) == 530 and len(idx) == 3 * 1024 and max(idx) == 529 and min(idx) == 0
+    import struct
+    assert pos[0] == tuple(struct.unpack("f", struct.pack("f", x))[0] for x in (40.6266, 28.3457, -1.10804))   # f32 then widened
+    assert idx[-3:] == [528, 529, 469]      # last face `f 529//529 530//530 470//470`
+
+
+def test_error_paths_return_errors(pbe):
+    b = SceneBuilder(pbe)
+    m = b.Lambertian(b.ConstantTexture((1, 1, 1)))
+    with pytest.raises(SceneError, match="no object in the scene"):      # src/bvh.rs:55 panics
+        b.BVH([], 0.0, 1.0)
+    assert pbe.lib.rt_sphere(b.h, (C.c_double * 3)(0, 0, 0), 1.0, 99) < 0
+    assert b"bad material" in pbe.lib.rt_last_error()
+    # a BVH child without a device leaf form
+    s = b.Sphere((0, 0, 0), 1.0, m)
+    world = b.BVH([b.Translate(s, (1, 0, 0))], 0.0, 1.0)
+    b.set_scene(world, [])
+    with pytest.raises(R.RenderError, match="unsupported BVH child"):
+        R.flatten(b)
+    # ConstantMedium must be the outermost wrapper
+    b2 = SceneBuilder(pbe)
+    s2 = b2.Sphere((0, 0, 0), 1.0, b2.Dielectric(1.5))
+    b2.set_scene(b2.Translate(b2.ConstantMedium(s2, 0.1, b2.ConstantTexture((1, 1, 1))), (1, 0, 0)), [])
+    with pytest.raises(R.RenderError, match="outermost"):
+        R.flatten(b2)
+    b3 = SceneBuilder(pbe)
+    with pytest.raises(R.RenderError, match="world not set"):
+        R.flatten(b3)
+
+
+def test_render_without_gpu_fails_loudly(pbe):
+    if R.device_count() > 0:
+        pytest.skip("a GPU is present")
+    b, cam, bg = scenes.cornell_box(pbe)
+    with pytest.raises(R.RenderError, match="no HIP device"):
+        R.render(b, cam, bg, 8, 8, 1, 5)
+
+
+def test_render_argument_checks(pbe):
+    b, cam, bg = scenes.cornell_box(pbe)
+    with pytest.raises(R.RenderError, match="W and H"):
+        R.render(b, cam, bg, 1, 8, 1, 5)
+    with pytest.raises(R.RenderError, match="samples_per_pixel"):
+        R.render(b, cam, bg, 8, 8, 0, 5)
+
+
+def test_local_tiles(pbe):
+    assert R.local_tiles(800, 800, 64, 0, 1) == 10000
+    assert R.local_tiles(800, 800, 64, 3, 8) == 1250
+    assert R.local_tiles(10, 10, 64, 1, 8) == 1          # 2 real tiles, padded to 1 per rank
+    assert R.local_tiles(1920, 1080, 64, 7, 8) == 4050

@@ -1,0 +1,249 @@
+"""GPU parity tests: the HIP path (through the C-ABI of librt_amd.so) against the CPU oracle on the same
+seeded inputs, against the committed golden fixtures, and — at BASELINE's full size — through
+size-independent properties.
+
+Tolerance (f64 kernel vs f64 oracle, same random stream): every +,-,*,/ and sqrt rounds identically on
+both sides (-ffp-contract=off); the differences left are (a) sin/cos/atan2/acos/log of the device math
+library vs glibc (<= a few ulp), (b) the kernel folds the throughput forward (beta *= w) while the
+reference's recursion multiplies on the way back (main.rs:97), (c) the order of the per-pixel sum.  All are
+O(depth * 1e-16) relative per sample, so:
+    per sample : |gpu - oracle| <= 1e-9 * (1 + |oracle|)   (NaN/inf must match in kind)
+    per pixel  : |gpu - oracle| <= 1e-9 * (spp + |oracle|)
+A path whose branch decision flips on a last-ulp difference would break this for that one sample; none is
+expected at these sizes (P ~ 1e-10 per sample) and at most MAX_DIVERGED are tolerated.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import build_scene
+from raytracinginrust_amd import _lib, dist as D, render as R, scenes
+from raytracinginrust_amd.api import Axis, Camera, Plane, SceneBuilder
+
+pytestmark = pytest.mark.gpu
+
+SAMPLE_RTOL = 1e-9
+MAX_DIVERGED = 2
+
+CASES = {  # name: (W, H, spp, depth)   — sizes the oracle finishes in seconds
+    "cornell": (48, 48, 32, 50),
+    "random": (64, 36, 16, 8),        # BASELINE config 1 shape (16:9, depth 8)
+    "final": (40, 40, 16, 50),
+    "teapot": (64, 36, 16, 50),
+}
+
+
+def _compare_samples(gs, rs):
+    """Returns (#diverged samples, max abs diff over the rest); NaN/inf patterns must be identical."""
+    assert gs.shape == rs.shape
+    assert np.array_equal(np.isnan(gs), np.isnan(rs))
+    assert np.array_equal(np.isposinf(gs), np.isposinf(rs)) and np.array_equal(np.isneginf(gs), np.isneginf(rs))
+    fin = np.isfinite(rs)
+    d = np.where(fin, np.abs(np.where(fin, gs, 0.0) - np.where(fin, rs, 0.0)), 0.0)
+    bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, rs, 0.0)))).any(axis=-1)
+    return int(bad.sum()), float(d[~bad].max()) if (~bad).any() else 0.0, bad
+
+
+@pytest.fixture(scope="module")
+def orc_mod():
+    from oracle import orc
+    orc.load()
+    return orc
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_scene_parity_per_sample_and_per_pixel(name, pbe, obe, orc_mod, earth):
+    W, H, spp, depth = CASES[name]
+    ob, ocam, obg = build_scene(name, obe, earth)
+    pb, pcam, pbg = build_scene(name, pbe, earth)
+    ref, rs, cnt = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True, want_counters=True)
+    got, gs = R.render(pb, pcam, pbg, W, H, spp, depth, want_samples=True)
+    n_bad, max_d, bad = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED, f"{n_bad} of {W * H * spp} samples diverged"
+    clean = ~bad.any(axis=-1)                                   # pixels without a diverged sample
+    fin = np.isfinite(ref)
+    dp = np.abs(np.where(fin, got, 0.0) - np.where(fin, ref, 0.0))
+    assert np.all(dp[clean] <= SAMPLE_RTOL * (spp + np.abs(np.where(fin, ref, 0.0))[clean]))
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+    # the 8-bit image the reference would print (vec.rs:125-131): identical up to quantisation-boundary ties
+    a, b = R.format_image(got, spp), R.format_image(ref, spp)
+    assert (a != b).sum() <= 3 and np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+@pytest.mark.parametrize("name", ["cornell", "random", "final", "teapot"])
+def test_against_committed_golden(name, pbe, earth):
+    g = np.load(scenes.asset_path(f"oracle_{name}.npz"))
+    W, H, spp, depth, seed = int(g["W"]), int(g["H"]), int(g["spp"]), int(g["depth"]), int(g["seed"])
+    pb, pcam, pbg = build_scene(name, pbe, earth)
+    got = R.render(pb, pcam, pbg, W, H, spp, depth, seed=seed)
+    ref = g["rgb_sum"]
+    assert np.all(np.abs(got - ref) <= SAMPLE_RTOL * (spp + np.abs(ref)))
+
+
+# ------------------------------------------------------------------ exact-value invariants on the GPU
+def test_white_furnace_exact(pbe):
+    b = SceneBuilder(pbe)
+    rho = (0.25, 0.5, 0.75)
+    world = b.HittableList()
+    world.push(b.Sphere((0.0, 0.0, 0.0), 1.0, b.Lambertian(b.ConstantTexture(rho))))
+    b.set_scene(world, [])
+    cam = Camera((0.0, 0.0, -4.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 4.0, 0.0, 1.0)
+    _, s = R.render(b, cam, (1.0, 1.0, 1.0), 64, 64, 16, 50, want_samples=True)
+    s = s.reshape(-1, 3)
+    hit = np.abs(s - np.array(rho)).max(axis=1) < 1e-14
+    miss = (s == 1.0).all(axis=1)
+    assert np.all(hit | miss) and hit.sum() > 1000 and miss.sum() > 1000
+
+
+def test_glass_furnace_exact(pbe):
+    b = SceneBuilder(pbe)
+    world = b.HittableList()
+    world.push(b.Sphere((0.0, 0.0, 0.0), 1.0, b.Dielectric(1.5)))
+    b.set_scene(world, [])
+    cam = Camera((0.0, 0.0, -4.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 4.0, 0.0, 1.0)
+    _, s = R.render(b, cam, (1.0, 1.0, 1.0), 64, 64, 16, 50, want_samples=True)
+    s = s.reshape(-1, 3)
+    ones, zeros = (s == 1.0).all(axis=1), (s == 0.0).all(axis=1)
+    assert np.all(ones | zeros) and ones.mean() > 0.999
+
+
+# ------------------------------------------------------------------ edge cases
+def _cornell(pbe):
+    return scenes.cornell_box(pbe)
+
+
+def test_minimum_frame_and_ragged_sample_counts(pbe, obe, orc_mod):
+    """W = H = 2 (u,v divide by W-1, H-1), spp = 1 and spp not a multiple of the wave width."""
+    for W, H, spp in [(2, 2, 1), (3, 2, 37), (5, 7, 65), (2, 9, 130)]:
+        ob, ocam, obg = scenes.cornell_box(obe)
+        pb, pcam, pbg = scenes.cornell_box(pbe)
+        ref = orc_mod.render(ob, ocam, obg, W, H, spp, 50)
+        got = R.render(pb, pcam, pbg, W, H, spp, 50)
+        assert np.all(np.abs(got - ref) <= SAMPLE_RTOL * (spp + np.abs(ref))), (W, H, spp)
+
+
+def test_depth_budget(pbe):
+    b, cam, bg = _cornell(pbe)
+    assert np.all(R.render(b, cam, bg, 16, 16, 8, 0) == 0.0)                    # main.rs:42-45
+    _, s = R.render(b, cam, bg, 32, 32, 8, 1, want_samples=True)
+    assert set(np.unique(s)) <= {0.0, 15.0}                                     # only the emitter is visible at depth 1
+
+
+def test_nan_samples_match_reference_semantics(pbe, obe, orc_mod):
+    """A `lights` entry with the trait-default pdf_value = 0 / random = (1,0,0) (hit.rs:29-30) makes the mixture
+    pdf 0 for grazing directions: weight = att * 0 / 0 = NaN (Appendix B8).  The kernel must poison the same samples,
+    and format_color must print them as 0."""
+    def build(be):
+        b = SceneBuilder(be)
+        white = b.Lambertian(b.ConstantTexture((0.73, 0.73, 0.73)))
+        floor = b.AARect(Plane.XZ, -100.0, 100.0, -100.0, 100.0, 0.0, white)
+        cube = b.Cube((-10.0, 0.0, -10.0), (10.0, 20.0, 10.0), white)       # Cube has no pdf_value/random of its own
+        world = b.HittableList()
+        world.push(floor)
+        world.push(cube)
+        b.set_scene(world, [cube])
+        cam = Camera((0.0, 50.0, -120.0), (0.0, 5.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+        return b, cam, (0.5, 0.7, 1.0)
+    ob, ocam, obg = build(obe)
+    pb, pcam, pbg = build(pbe)
+    ref, rs, cnt = orc_mod.render(ob, ocam, obg, 32, 32, 8, 10, want_samples=True, want_counters=True)
+    got, gs = R.render(pb, pcam, pbg, 32, 32, 8, 10, want_samples=True)
+    assert cnt["nonfinite"] > 100                                              # the case is actually exercised
+    n_bad, _, _ = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED
+    assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+    assert np.array_equal(R.format_image(got, 8), R.format_image(ref, 8))
+
+
+def test_sphere_light_and_wrapped_instances(pbe, obe, orc_mod):
+    """Sphere as a light (sphere.rs:104-119), Rotate about X and Z, FlipNormal outside a Translate, a Mesh list
+    used directly (no BVH), a ConstantMedium around a rotated box."""
+    def build(be):
+        b = SceneBuilder(be)
+        white = b.Lambertian(b.ConstantTexture((0.73, 0.73, 0.73)))
+        blue = b.Lambertian(b.ConstantTexture((0.2, 0.3, 0.8)))
+        glow = b.DiffuseLight(b.ConstantTexture((9.0, 8.0, 7.0)))
+        bulb = b.Sphere((0.0, 60.0, 0.0), 8.0, glow)
+        world = b.HittableList()
+        world.push(b.AARect(Plane.XZ, -100.0, 100.0, -100.0, 100.0, 0.0, white))
+        world.push(bulb)
+        world.push(b.Rotate(Axis.X, b.Cube((-30.0, 0.0, -10.0), (-10.0, 20.0, 10.0), blue), 20.0))
+        world.push(b.Translate(b.Rotate(Axis.Z, b.Cube((0.0, 0.0, 0.0), (15.0, 25.0, 15.0), b.Metal((0.9, 0.9, 0.9), 0.2)), -25.0), (20.0, 0.0, -5.0)))
+        world.push(b.FlipNormal(b.Translate(b.AARect(Plane.XY, -40.0, 40.0, 0.0, 50.0, 0.0, white), (0.0, 0.0, 60.0))))
+        world.push(b.Mesh([(-50.0, 0.0, 30.0), (-30.0, 0.0, 30.0), (-40.0, 30.0, 35.0), (-40.0, 10.0, 10.0)], [0, 1, 2, 0, 2, 3, 1, 2, 3], blue))
+        smoke_box = b.Translate(b.Rotate(Axis.Y, b.Cube((0.0, 0.0, 0.0), (20.0, 20.0, 20.0), white), 30.0), (-5.0, 0.0, -40.0))
+        world.push(b.ConstantMedium(smoke_box, 0.05, b.ConstantTexture((1.0, 1.0, 1.0))))
+        b.set_scene(world, [bulb])
+        cam = Camera((0.0, 70.0, -160.0), (0.0, 20.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.5, 170.0, 0.0, 1.0)
+        return b, cam, (0.02, 0.02, 0.05)
+    ob, ocam, obg = build(obe)
+    pb, pcam, pbg = build(pbe)
+    ref, rs = orc_mod.render(ob, ocam, obg, 48, 48, 16, 30, want_samples=True)
+    got, gs = R.render(pb, pcam, pbg, 48, 48, 16, 30, want_samples=True)
+    n_bad, _, _ = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED
+    assert ref.mean() > 0.0
+
+
+def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
+    b, cam, bg = _cornell(pbe)
+    a = R.render(b, cam, bg, 64, 64, 32, 50)
+    c = R.render(b, cam, bg, 64, 64, 32, 50, flags=R.RT_STOP_ON_ZERO)
+    assert np.all(np.abs(a - c) <= 1e-12 * (32 + np.abs(a)))
+
+
+# ------------------------------------------------------------------ tile sharding on one GPU
+@pytest.mark.parametrize("world,tile_px", [(1, 64), (3, 64), (8, 100), (2, 7)])
+def test_tile_sharded_render_reassembles_to_full_frame(pbe, world, tile_px):
+    import torch
+    b, cam, bg = _cornell(pbe)
+    W, H, spp, depth = 50, 30, 16, 50
+    full = R.render(b, cam, bg, W, H, spp, depth)
+    parts = []
+    for rank in range(world):
+        tr = D.TileRenderer(b, cam, bg, W, H, spp, depth, tile_px=tile_px, rank=rank, world=world)
+        parts.append(tr.render_local().clone())
+    torch.cuda.synchronize()
+    frame = D.assemble(torch.stack(parts, 0), W, H, tile_px).cpu().numpy()
+    assert np.all(np.abs(frame - full) <= 1e-12 * (spp + np.abs(full)))
+
+
+# ------------------------------------------------------------------ BASELINE's full size: size-independent properties
+def test_full_size_cornell_properties(pbe, obe, orc_mod):
+    """BASELINE config 2: Cornell box 800x800, 1024 spp, depth 50.  The oracle cannot run this in seconds, so:
+    (1) two runs agree to summation-order rounding (the dynamic sample->lane assignment changes only the order);
+    (2) no non-finite sample; (3) the frame mean equals the oracle's mean over a coarser grid of the same
+    image within Monte-Carlo error; (4) a sharded render (8 ranks) reassembles to the same frame."""
+    import torch
+    b, cam, bg = _cornell(pbe)
+    W = H = 800
+    spp, depth = 1024, 50
+    a = R.render(b, cam, bg, W, H, spp, depth)
+    ms = R.last_kernel_ms(b)
+    assert R.last_stats(b)["nonfinite_samples"] == 0
+    c = R.render(b, cam, bg, W, H, spp, depth)
+    assert np.all(np.abs(a - c) <= 1e-12 * (spp + np.abs(a)))
+    ob, ocam, obg = scenes.cornell_box(obe)
+    coarse = orc_mod.render(ob, ocam, obg, 100, 100, 64, depth, seed=7)
+    assert a.mean() / spp == pytest.approx(coarse.mean() / 64, rel=0.02)
+    parts = []
+    for rank in range(8):
+        tr = D.TileRenderer(b, cam, bg, W, H, spp, depth, tile_px=64, rank=rank, world=8)
+        parts.append(tr.render_local().clone())
+    torch.cuda.synchronize()
+    frame = D.assemble(torch.stack(parts, 0), W, H, 64).cpu().numpy()
+    assert np.all(np.abs(frame - a) <= 1e-12 * (spp + np.abs(a)))
+    print(f"C2 800x800x1024 f64: {ms:.1f} ms, {W * H * spp / ms / 1e3:.0f} Msamples/s")
+
+
+def test_f32_variant_statistical_parity(pbe):
+    """RT_F32 is the throughput variant: same estimator in f32, so only statistical agreement is claimed."""
+    b, cam, bg = _cornell(pbe)
+    a = R.render(b, cam, bg, 200, 200, 256, 50) / 256
+    c = R.render(b, cam, bg, 200, 200, 256, 50, flags=R.RT_F32) / 256
+    assert np.all(np.isfinite(c))
+    assert c.mean() == pytest.approx(a.mean(), rel=0.03)
+    blocks = lambda x: x.reshape(10, 20, 10, 20, 3).mean(axis=(1, 3))
+    assert np.abs(blocks(a) - blocks(c)).max() < 0.06
