@@ -1,0 +1,13 @@
+"""Summarise rocprofv3 --pmc CSVs: per counter, the mean over dispatches of the path-tracing kernel."""
+import csv, glob, os, sys, collections
+root = sys.argv[1]
+res = collections.OrderedDict()
+for f in sorted(glob.glob(os.path.join(root, '*', '*', '*counter_collection.csv'))):
+    for r in csv.DictReader(open(f)):
+        if 'pathtrace' not in r['Kernel_Name']: continue
+        res.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
+out = []
+for k, v in res.items():
+    out.append(f"{k},{sum(v)/len(v):.6g},{len(v)}")
+open(os.path.join(root, 'summary.csv'), 'w').write("counter,mean_per_dispatch,dispatches\n" + "\n".join(out) + "\n")
+print("\n".join(out))
