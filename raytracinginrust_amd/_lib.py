@@ -24,11 +24,17 @@ def load() -> Backend:
     global _backend
     if _backend is not None:
         return _backend
-    if not os.path.exists(LIB_PATH):
+    _backend = load_path(LIB_PATH)
+    return _backend
+
+
+def load_path(path: str) -> Backend:
+    """Load a specific build of the library (tools/ab.py compares kernel variants in one process)."""
+    if not os.path.exists(path):
         raise LibraryMissing(
-            f"{LIB_PATH} is missing: build it with `make -C raytracinginrust_amd/csrc` "
+            f"{path} is missing: build it with `make -C raytracinginrust_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     be = Backend(lib, "rt_")
     cam_p = C.POINTER(CameraParams)
     lib.rt_last_error.restype = C.c_char_p
@@ -50,5 +56,4 @@ def load() -> Backend:
     lib.rt_last_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     lib.rt_write_ppm.restype = C.c_int
     lib.rt_write_ppm.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]
-    _backend = be
     return be

@@ -47,8 +47,26 @@ template <typename T> DEV T sq_of_len(V3<T> a) { T l = length(a); return l * l; 
 template <typename T> DEV T get(V3<T> v, uint32_t k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
 template <typename T> DEV V3<T> ld3(const T* p) { return mk<T>(p[0], p[1], p[2]); }
 
+// Scene tables are immutable for the whole launch: read them through the constant address space, so that a
+// wave-uniform index becomes a scalar load (s_load, no VGPRs, scalar cache) and a per-lane index a plain gather.
+#define CAS __attribute__((address_space(4)))
+template <typename F> DEV F cl(const F* p) { return *(const CAS F*)p; }
+template <typename T> DEV V3<T> cl3(const T* p) { return mk<T>(cl(p), cl(p + 1), cl(p + 2)); }
+template <typename T> DEV DRect<T> ld_rect(const DRect<T>* p) { DRect<T> r; r.a0 = cl(&p->a0); r.a1 = cl(&p->a1); r.b0 = cl(&p->b0); r.b1 = cl(&p->b1); r.k = cl(&p->k); r.plane = cl(&p->plane); r.mat = cl(&p->mat); return r; }
+template <typename T> DEV DSphere<T> ld_sphere(const DSphere<T>* p) { DSphere<T> r; r.c[0] = cl(&p->c[0]); r.c[1] = cl(&p->c[1]); r.c[2] = cl(&p->c[2]); r.r = cl(&p->r); r.mat = cl(&p->mat); r.pad = 0; return r; }
+template <typename T> DEV DMSphere<T> ld_msphere(const DMSphere<T>* p) { DMSphere<T> r; for (int k = 0; k < 3; k++) { r.c0[k] = cl(&p->c0[k]); r.c1[k] = cl(&p->c1[k]); } r.t0 = cl(&p->t0); r.t1 = cl(&p->t1); r.r = cl(&p->r); r.mat = cl(&p->mat); r.pad = 0; return r; }
+template <typename T> DEV DTri<T> ld_tri(const DTri<T>* p) { DTri<T> r; for (int k = 0; k < 3; k++) { r.v0[k] = cl(&p->v0[k]); r.e1[k] = cl(&p->e1[k]); r.e2[k] = cl(&p->e2[k]); } r.mat = cl(&p->mat); r.pad = 0; return r; }
+template <typename T> DEV DOp<T> ld_op(const DOp<T>* p) { DOp<T> r; r.kind = cl(&p->kind); r.axis = cl(&p->axis); r.x = cl(&p->x); r.y = cl(&p->y); r.z = cl(&p->z); return r; }
+DEV DObject ld_obj(const DObject* p) { DObject r; r.geom_kind = cl(&p->geom_kind); r.geom_first = cl(&p->geom_first); r.geom_count = cl(&p->geom_count); r.first_op = cl(&p->first_op); r.n_ops = cl(&p->n_ops); r.medium = cl(&p->medium); r.pad0 = r.pad1 = 0; return r; }
+template <typename T> DEV DBvhNode<T> ld_node(const DBvhNode<T>* p) { DBvhNode<T> r; for (int k = 0; k < 3; k++) { r.mn[k] = cl(&p->mn[k]); r.mx[k] = cl(&p->mx[k]); } r.a = cl(&p->a); r.b = cl(&p->b); return r; }
+template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r; r.kind = cl(&p->kind); r.tex = cl(&p->tex); for (int k = 0; k < 3; k++) r.albedo[k] = cl(&p->albedo[k]); r.param = cl(&p->param); return r; }
+template <typename T> DEV DTexture<T> ld_tex(const DTexture<T>* p) { DTexture<T> r; r.kind = cl(&p->kind); r.a = cl(&p->a); r.b = cl(&p->b); r.c = cl(&p->c); for (int k = 0; k < 3; k++) r.color[k] = cl(&p->color[k]); r.scale = cl(&p->scale); return r; }
+DEV DLight ld_light(const DLight* p) { DLight r; r.kind = cl(&p->kind); r.index = cl(&p->index); return r; }
+
 DEV double m_sin(double x) { return ::sin(x); }   DEV float m_sin(float x) { return ::sinf(x); }
 DEV double m_cos(double x) { return ::cos(x); }   DEV float m_cos(float x) { return ::cosf(x); }
+DEV void m_sincos(double x, double& sn, double& cs) { ::sincos(x, &sn, &cs); }   // same reduction + polynomials as sin() and cos()
+DEV void m_sincos(float x, float& sn, float& cs) { ::sincosf(x, &sn, &cs); }
 DEV double m_log(double x) { return ::log(x); }   DEV float m_log(float x) { return ::logf(x); }
 DEV double m_acos(double x) { return ::acos(x); } DEV float m_acos(float x) { return ::acosf(x); }
 DEV double m_atan2(double y, double x) { return ::atan2(y, x); } DEV float m_atan2(float y, float x) { return ::atan2f(y, x); }
@@ -135,22 +153,22 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
     if (kind == G_RECT) {
         for (uint32_t i = first; i < first + count; i++) {
             T t;
-            if (rect_test(P.rects[i], ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
+            if (rect_test(ld_rect(P.rects + i), ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
         }
     } else if ((FEATS & F_SPHERES) && kind == G_SPHERE) {
         for (uint32_t i = first; i < first + count; i++) {
-            T t; const DSphere<T>& s = P.spheres[i];
+            T t; const DSphere<T> s = ld_sphere(P.spheres + i);
             if (sphere_test(ld3(s.c), s.r, ray, t_min, closest, t)) { closest = t; prim_out = (G_SPHERE << 28) | i; any = true; }
         }
     } else if ((FEATS & F_SPHERES) && kind == G_MSPHERE) {
         for (uint32_t i = first; i < first + count; i++) {
-            T t; const DMSphere<T>& s = P.mspheres[i];
+            T t; const DMSphere<T> s = ld_msphere(P.mspheres + i);
             if (sphere_test(msphere_center(s, ray.tm), s.r, ray, t_min, closest, t)) { closest = t; prim_out = (G_MSPHERE << 28) | i; any = true; }
         }
     } else if ((FEATS & F_TRIS) && kind == G_TRI) {
         for (uint32_t i = first; i < first + count; i++) {
             T t, b1, b2;
-            if (tri_test(P.tris[i], ray, t_min, closest, t, b1, b2)) { closest = t; prim_out = (G_TRI << 28) | i; any = true; }
+            if (tri_test(ld_tri(P.tris + i), ray, t_min, closest, t, b1, b2)) { closest = t; prim_out = (G_TRI << 28) | i; any = true; }
         }
     }
     t_out = closest;
@@ -169,7 +187,7 @@ DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min
     uint32_t node = root;
     uint32_t sp = 0;
     for (;;) {
-        const DBvhNode<T> nd = P.bvh[node];
+        const DBvhNode<T> nd = ld_node(P.bvh + node);
         bool inside = true;
         {
             T t_in = t_min, t_o = closest;
@@ -237,9 +255,9 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
     T closest = Lim<T>::inf();
     bool any = false;
     for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
-        const DObject ob = P.objects[oi];
+        const DObject ob = ld_obj(P.objects + oi);
         RayT<T> r = ray;
-        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(P.ops[ob.first_op + k], r);
+        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
         if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
             T t; uint32_t prim;
             if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
@@ -253,7 +271,7 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
                     if (t1 < t2) {
                         T len = length(ray.d);
                         T distance_inside_boundary = (t2 - t1) * len;
-                        T hit_distance = P.media[ob.medium].neg_inv_density * m_log(rng_u01(rng, T(0)));
+                        T hit_distance = cl(&P.media[ob.medium].neg_inv_density) * m_log(rng_u01(rng, T(0)));
                         if (hit_distance < distance_inside_boundary) {
                             closest = t1 + hit_distance / len;
                             id.obj = oi; id.prim = PRIM_MEDIUM; any = true;
@@ -279,20 +297,20 @@ template <typename T> DEV void sphere_uv(V3<T> p, T& u, T& v) {
 // eagerly inside every `hit`, run once.  Per-lane gathers: lanes may hold different objects.
 template <typename T, uint32_t FEATS>
 DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bool want_uv, Rec<T>& rec) {
-    const DObject ob = P.objects[id.obj];
+    const DObject ob = ld_obj(P.objects + id.obj);
     rec.t = t; rec.u = T(0); rec.v = T(0);
     if ((FEATS & F_MEDIUM) && id.prim == PRIM_MEDIUM) {                               // medium.rs:45-55
         rec.p = ray_at(ray, t);
         rec.n = mk<T>(T(1.0), T(0), T(0));
         rec.front = false;
-        rec.mat = P.media[ob.medium].mat;
+        rec.mat = cl(&P.media[ob.medium].mat);
         return;
     }
     RayT<T> r = ray;
-    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(P.ops[ob.first_op + k], r);
+    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     const uint32_t kind = id.prim >> 28, idx = id.prim & 0x0FFFFFFFu;
     if (kind == G_RECT) {                                                             // rect.rs:61-79
-        const DRect<T> rc = P.rects[idx];
+        const DRect<T> rc = ld_rect(P.rects + idx);
         uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
         if ((FEATS & F_TEXTURES) && want_uv) {
             T a = get(r.o, ai) + t * get(r.d, ai);
@@ -306,14 +324,14 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         rec.mat = rc.mat;
     } else if ((FEATS & F_SPHERES) && (kind == G_SPHERE || kind == G_MSPHERE)) {      // sphere.rs:76-94, :170-188
         V3<T> center; T radius;
-        if (kind == G_SPHERE) { const DSphere<T> s = P.spheres[idx]; center = ld3(s.c); radius = s.r; rec.mat = s.mat; }
-        else { const DMSphere<T> s = P.mspheres[idx]; center = msphere_center(s, r.tm); radius = s.r; rec.mat = s.mat; }
+        if (kind == G_SPHERE) { const DSphere<T> s = ld_sphere(P.spheres + idx); center = ld3(s.c); radius = s.r; rec.mat = s.mat; }
+        else { const DMSphere<T> s = ld_msphere(P.mspheres + idx); center = msphere_center(s, r.tm); radius = s.r; rec.mat = s.mat; }
         rec.p = ray_at(r, t);
         V3<T> outward = (rec.p - center) / radius;
         set_face_normal(rec, r.d, outward);
         if ((FEATS & F_TEXTURES) && want_uv) sphere_uv(outward, rec.u, rec.v);
     } else if ((FEATS & F_TRIS) && kind == G_TRI) {                                   // tri.rs:42-56
-        const DTri<T> tr = P.tris[idx];
+        const DTri<T> tr = ld_tri(P.tris + idx);
         V3<T> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
         if ((FEATS & F_TEXTURES) && want_uv) {
             V3<T> s = r.o - ld3(tr.v0);
@@ -330,12 +348,12 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
     }
     // unwind the wrapper chain innermost -> outermost
     for (int k = (int)ob.n_ops - 1; k >= 0; k--) {
-        const DOp<T> op = P.ops[ob.first_op + (uint32_t)k];
+        const DOp<T> op = ld_op(P.ops + ob.first_op + (uint32_t)k);
         if (op.kind == OP_TRANSLATE) {
             rec.p = rec.p + mk<T>(op.x, op.y, op.z);                                  // translate.rs:26
         } else if (op.kind == OP_ROTATE) {                                            // rotate.rs:90-104
             RayT<T> rr = ray;                                                         // the ray this Rotate handed to its child
-            for (int q = 0; q <= k; q++) op_fwd(P.ops[ob.first_op + (uint32_t)q], rr);
+            for (int q = 0; q <= k; q++) op_fwd(ld_op(P.ops + ob.first_op + (uint32_t)q), rr);
             rot_back(op.axis, op.x, op.y, rec.p);
             V3<T> nw = rec.n;
             rot_back(op.axis, op.x, op.y, nw);
@@ -369,8 +387,8 @@ template <typename T> DEV T perlin_noise(const DPerlin<T>& pn, V3<T> p, T scale)
         for (uint32_t dj = 0; dj < 2; dj++)
 #pragma unroll
             for (uint32_t dk = 0; dk < 2; dk++) {
-                uint32_t h = (uint32_t)pn.perm_x[(i + di) & 255u] ^ (uint32_t)pn.perm_y[(j + dj) & 255u] ^ (uint32_t)pn.perm_z[(k + dk) & 255u];
-                V3<T> c = ld3(&pn.rd_vec[h * 3u]);
+                uint32_t h = (uint32_t)cl(&pn.perm_x[(i + di) & 255u]) ^ (uint32_t)cl(&pn.perm_y[(j + dj) & 255u]) ^ (uint32_t)cl(&pn.perm_z[(k + dk) & 255u]);
+                V3<T> c = cl3(&pn.rd_vec[h * 3u]);
                 V3<T> weight = mk<T>(u - T(di), v - T(dj), w - T(dk));
                 T fu = di ? uu : (T(1.0) - uu), fv = dj ? vv : (T(1.0) - vv), fw = dk ? ww : (T(1.0) - ww);
                 accum += fu * fv * fw * dot(c, weight);
@@ -393,7 +411,7 @@ template <typename T> DEV T clamp_(T x, T lo, T hi) { return x < lo ? lo : (x > 
 template <typename T, uint32_t FEATS>
 DEV V3<T> tex_eval(const KParams<T>& P, uint32_t id, T u, T v, V3<T> p) {             // Texture::mapping, texture.rs:5-7
     for (;;) {
-        const DTexture<T> tx = P.textures[id];
+        const DTexture<T> tx = ld_tex(P.textures + id);
         if (!(FEATS & F_TEXTURES) || tx.kind == T_CONSTANT) return ld3(tx.color);     // texture.rs:23-27
         if (tx.kind == T_CHECK) {                                                     // texture.rs:45-54
             T sines = m_sin(T(10.0) * p.x) * m_sin(T(10.0) * p.y) * m_sin(T(10.0) * p.z);
@@ -411,7 +429,7 @@ DEV V3<T> tex_eval(const KParams<T>& P, uint32_t id, T u, T v, V3<T> p) {       
         if (i > w - 1) i = w - 1;
         if (j > h - 1) j = h - 1;
         const uint8_t* px = P.image_bytes + tx.a + 3ull * i + 3ull * w * j;
-        return mk<T>(T(px[0]) / T(255.0), T(px[1]) / T(255.0), T(px[2]) / T(255.0));
+        return mk<T>(T(cl(px)) / T(255.0), T(cl(px + 1)) / T(255.0), T(cl(px + 2)) / T(255.0));
     }
 }
 
@@ -432,22 +450,24 @@ template <typename T> DEV V3<T> random_cosine_direction(Rng& rng) {             
     T r2 = rng_u01(rng, T(0));
     T z = rsqrt_(T(1.0) - r2);
     T phi = T(2.0) * PI_T * r1;
-    T x = m_cos(phi) * rsqrt_(r2);
-    T y = m_sin(phi) * rsqrt_(r2);
+    T sn, cs; m_sincos(phi, sn, cs);
+    T x = cs * rsqrt_(r2);
+    T y = sn * rsqrt_(r2);
     return mk<T>(x, y, z);
 }
 template <typename T> DEV V3<T> random_in_unit_sphere(Rng& rng) {                     // vec.rs:78-85
     for (;;) {
         T a = rng_range(rng, T(-1.0), T(1.0)), b = rng_range(rng, T(-1.0), T(1.0)), c = rng_range(rng, T(-1.0), T(1.0));
         V3<T> v = mk<T>(a, b, c);
-        if (length(v) < T(1.0)) return v;
+        // vec.rs:81 tests `v.length() < 1.0`; for a correctly rounded sqrt, sqrt(x) < 1 <=> x < 1, so the sqrt is skipped
+        if (dot(v, v) < T(1.0)) return v;
     }
 }
 
 template <typename T, uint32_t FEATS> DEV T light_pdf_value(const KParams<T>& P, DLight L, V3<T> o, V3<T> v) {
     RayT<T> r; r.o = o; r.d = v; r.tm = T(0);
     if (L.kind == L_RECT) {                                                           // rect.rs:91-101
-        const DRect<T> rc = P.rects[L.index];
+        const DRect<T> rc = ld_rect(P.rects + L.index);
         T t;
         if (rect_test(rc, r, T(0.001), Lim<T>::inf(), t)) {
             uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
@@ -461,7 +481,7 @@ template <typename T, uint32_t FEATS> DEV T light_pdf_value(const KParams<T>& P,
         return T(0);
     }
     if ((FEATS & F_SPHERES) && L.kind == L_SPHERE) {                                  // sphere.rs:104-112
-        const DSphere<T> s = P.spheres[L.index];
+        const DSphere<T> s = ld_sphere(P.spheres + L.index);
         T t;
         if (sphere_test(ld3(s.c), s.r, r, T(0.001), Lim<T>::max(), t)) {
             T cos_theta_max = rsqrt_(T(1.0) - s.r * s.r / sq_of_len(ld3(s.c) - o));
@@ -474,7 +494,7 @@ template <typename T, uint32_t FEATS> DEV T light_pdf_value(const KParams<T>& P,
 }
 template <typename T, uint32_t FEATS> DEV V3<T> light_random(const KParams<T>& P, DLight L, V3<T> o, Rng& rng) {
     if (L.kind == L_RECT) {                                                           // rect.rs:103-111
-        const DRect<T> rc = P.rects[L.index];
+        const DRect<T> rc = ld_rect(P.rects + L.index);
         uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
         T ra = rng_range(rng, rc.a0, rc.a1);
         T rb = rng_range(rng, rc.b0, rc.b1);
@@ -485,7 +505,7 @@ template <typename T, uint32_t FEATS> DEV V3<T> light_random(const KParams<T>& P
         return pt - o;
     }
     if ((FEATS & F_SPHERES) && L.kind == L_SPHERE) {                                  // sphere.rs:114-119, :27-36
-        const DSphere<T> s = P.spheres[L.index];
+        const DSphere<T> s = ld_sphere(P.spheres + L.index);
         V3<T> direction = ld3(s.c) - o;
         T distance_squared = sq_of_len(direction);
         Onb<T> uvw = onb_from_w(direction);
@@ -532,7 +552,7 @@ DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out,
 
 // ------------------------------------------------------------------ the kernel
 template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
+__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(const KParams<T> P) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (P.stack_depth * 64u) + lane;
@@ -541,9 +561,19 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
     const uint32_t n_px = P.W * P.H;
     const uint32_t NONE = 0xFFFFFFFFu;
 
-    // wave-uniform queue cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px
+    // wave-uniform queue cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px.
+    // cur_gp / cur_i / cur_j: the cursor pixel's global index and image coordinates, recomputed (wave-uniform,
+    // once per pixel, not per sample) whenever the cursor moves.
     uint32_t cur_px = 0, end_px = 0, cur_s = 0;
+    uint32_t cur_gp = 0, cur_i = 0, cur_j = 0;
     bool queue_done = false;
+    auto locate = [&]() {                 // local pixel -> global output-order pixel (tile t = rank + q * world)
+        uint32_t q = cur_px / P.tile_px, kk = cur_px - q * P.tile_px;
+        cur_gp = (P.rank + q * P.world) * P.tile_px + kk;
+        uint32_t row = cur_gp / P.W;
+        cur_i = cur_gp - row * P.W;
+        cur_j = P.H - 1u - row;           // row 0 is j = H-1, main.rs:772
+    };
 
     // per-lane path state
     bool alive = false;
@@ -560,7 +590,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
     for (;;) {
         // ---- hand the next samples to lanes whose path has ended
         bool got_new = false;
-        uint32_t new_px = 0, new_s = 0;
+        uint32_t new_px = 0, new_s = 0, new_gp = 0, new_i = 0, new_j = 0;
         for (;;) {
             unsigned long long want = __ballot(!alive && !got_new);
             if (want == 0) break;
@@ -573,14 +603,15 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
                 cur_px = c * P.chunk_px;
                 end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
                 cur_s = 0;
+                locate();
             }
             uint32_t avail = P.spp - cur_s;
             uint32_t n_want = (uint32_t)__popcll(want);
             uint32_t take = n_want < avail ? n_want : avail;
             uint32_t rank = lane_rank(want);
-            if (!alive && !got_new && rank < take) { got_new = true; new_px = cur_px; new_s = cur_s + rank; }
+            if (!alive && !got_new && rank < take) { got_new = true; new_px = cur_px; new_s = cur_s + rank; new_gp = cur_gp; new_i = cur_i; new_j = cur_j; }
             cur_s += take;
-            if (cur_s == P.spp) { cur_px++; cur_s = 0; }
+            if (cur_s == P.spp) { cur_px++; cur_s = 0; if (cur_px != end_px) locate(); }
         }
         if (__ballot(alive || got_new) == 0) break;     // queue empty and every path finished
 
@@ -590,11 +621,8 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
             path_px = new_px; path_s = new_s;
-            // local pixel -> global output-order pixel (tile t = rank + q * world)
-            uint32_t q = new_px / P.tile_px, kk = new_px - q * P.tile_px;
-            uint32_t gp = (P.rank + q * P.world) * P.tile_px + kk;
+            const uint32_t gp = new_gp, i = new_i, j = new_j;
             if (gp < n_px) {
-                uint32_t row = gp / P.W, i = gp - row * P.W, j = P.H - 1u - row;       // row 0 is j = H-1, main.rs:772
                 rng = rng_for_path(P.seed, gp, new_s);
                 // main.rs:813-820
                 T random_u = rng_u01(rng, T(0));
@@ -607,7 +635,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
                     da = rng_range(rng, T(-1.0), T(1.0));
                     db = rng_range(rng, T(-1.0), T(1.0));
                     V3<T> pd = mk<T>(da, db, T(0));
-                    if (length(pd) < T(1.0)) break;
+                    if (dot(pd, pd) < T(1.0)) break;       // `p.length() < 1.0` (vec.rs:101): sqrt(x) < 1 <=> x < 1
                 }
                 V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
                 V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
@@ -638,7 +666,7 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
                     // material of the hit decides whether (u,v) are needed at all
                     Rec<T> rec;
                     finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
-                    const DMaterial<T> mt = P.materials[rec.mat];
+                    const DMaterial<T> mt = ld_mat(P.materials + rec.mat);
                     if (mt.kind == M_LAMBERTIAN) {                                          // mat.rs:225-249, main.rs:92-98
                         V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
                         Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::cosine_pdf, pdf.rs:81-85
@@ -650,12 +678,12 @@ __global__ void __launch_bounds__(256) pathtrace_kernel(const KParams<T> P) {
                         } else {
                             if (rng_bool(rng)) {                                            // pdf.rs:167-173
                                 uint32_t li = rng_index(rng, P.n_lights);                   // hit.rs:94-96
-                                dir = light_random<T, FEATS>(P, P.lights[li], rec.p, rng);
+                                dir = light_random<T, FEATS>(P, ld_light(P.lights + li), rec.p, rng);
                             } else {
                                 dir = onb_local(uvw, random_cosine_direction<T>(rng));
                             }
                             T lsum = T(0);                                                  // hit.rs:90-92
-                            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, P.lights[li], rec.p, dir);
+                            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
                             T lpdf = lsum / T(P.n_lights);
                             T cosine = dot(normalized(dir), uvw.w);                         // pdf.rs:131-139
                             T cpdf = (cosine > T(0)) ? cosine / PI_T : T(0);
