@@ -273,7 +273,7 @@ template <typename T> void cv(const DMedium<double>& a, DMedium<T>& b) { b.neg_i
 template <typename DT, typename ST> int upload_vec(const std::vector<ST>& src, void*& dst) {
     dst = nullptr;
     size_t n = src.size();
-    std::vector<DT> tmp(n ? n : 1);
+    std::vector<DT> tmp(n + 1);            // one zeroed padding record: the kernel prefetches record i+1
     std::memset((void*)tmp.data(), 0, tmp.size() * sizeof(DT));
     for (size_t i = 0; i < n; i++) cv(src[i], tmp[i]);
     HIP_OK(hipMalloc(&dst, tmp.size() * sizeof(DT)));
@@ -352,7 +352,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.chunk_px = spp >= 256 ? 1u : (256u + spp - 1) / spp;
     P.n_chunks = (uint32_t)((n_local_px + P.chunk_px - 1) / P.chunk_px);
     if (!s.d_queue) HIP_OK(hipMalloc(&s.d_queue, 64));
-    if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 64));
+    if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 128));
     if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
     if (!s.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_stop = e; }
     P.queue = (uint32_t*)s.d_queue; P.stats = (unsigned long long*)s.d_stats;
@@ -360,7 +360,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
 
     int dev = 0; HIP_OK(hipGetDevice(&dev));
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, dev));
-    size_t shmem = (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
+    size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     uint64_t waves_needed = (n_local_px * spp + 63) / 64;
@@ -370,7 +370,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     if (n_blocks == 0) n_blocks = 1;
 
     HIP_OK(hipMemsetAsync(s.d_queue, 0, 64, stream));
-    HIP_OK(hipMemsetAsync(s.d_stats, 0, 64, stream));
+    HIP_OK(hipMemsetAsync(s.d_stats, 0, 128, stream));
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)n_local_px * 3 * sizeof(double), stream));
     HIP_OK(hipEventRecord((hipEvent_t)s.ev_start, stream));
     HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
@@ -418,6 +418,13 @@ int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {
     if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
     HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
     HIP_OK(hipMemcpy(out, sc->s.d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+// diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections; zeros otherwise
+int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[6]) {
+    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
+    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
+    HIP_OK(hipMemcpy(out, (char*)sc->s.d_stats + 3 * sizeof(unsigned long long), 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -67,6 +67,49 @@ DEV double m_sin(double x) { return ::sin(x); }   DEV float m_sin(float x) { ret
 DEV double m_cos(double x) { return ::cos(x); }   DEV float m_cos(float x) { return ::cosf(x); }
 DEV void m_sincos(double x, double& sn, double& cs) { ::sincos(x, &sn, &cs); }   // same reduction + polynomials as sin() and cos()
 DEV void m_sincos(float x, float& sn, float& cs) { ::sincosf(x, &sn, &cs); }
+
+// sin and cos of phi = 2*pi*r1 in [0, 2*pi) (pdf.rs:12-15, sphere.rs:31-33).  The general-purpose device sincos spends most
+// of its ~150 instructions on argument reduction for arbitrary magnitudes; here the range is known, so: k = nearest
+// integer to phi * 2/pi (0..4), r = phi - k*pi/2 with a two-word pi/2 (Cody-Waite, exact products via fma), then the
+// classic minimax kernels on [-pi/4, pi/4] (coefficients of the fdlibm __kernel_sin/__kernel_cos polynomials).  Measured
+// on the host against long double over 2e7 arguments: max error 0.78 ulp, 96.9 % of results bit-equal to glibc — the same
+// class as the device libm (neither is correctly rounded); f64 only.
+DEV void sincos_0_2pi(double phi, double& sn, double& cs) {
+    const double two_over_pi = 6.36619772367581382433e-01;
+    const double pio2_hi = 1.57079632673412561417e+00;     // first 33 bits of pi/2
+    const double pio2_lo = 6.07710050630396597660e-11;     // next 33 bits (k * pio2_lo is exact for k <= 4)
+    const double pio2_lo2 = 2.02226624879595063154e-21;    // pi/2 - (pio2_hi + pio2_lo)
+    double kf = __builtin_rint(phi * two_over_pi);
+    int k = (int)kf;
+    double r = __builtin_fma(-kf, pio2_hi, phi);            // exact: kf <= 4 and pio2_hi has 33 significant bits
+    double w = kf * pio2_lo;
+    double r1 = r - w;
+    double c = (r - r1) - w;                                // rounding error of r - w
+    c = __builtin_fma(-kf, pio2_lo2, c);
+    double x = r1 + c;                                      // reduced argument, |x| <= pi/4 (+ ulp)
+    double y = c - (x - r1);                                // its tail
+    double z = x * x;
+    // sin kernel
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double v = z * x;
+    double rs = __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, S6, S5), S4), S3), S2);
+    double s_ = x - ((z * (0.5 * y - v * rs) - y) - v * S1);
+    // cos kernel
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double rc = z * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, C6, C5), C4), C3), C2), C1);
+    double hz = 0.5 * z;
+    double wv = 1.0 - hz;
+    double c_ = wv + (((1.0 - wv) - hz) + (z * rc - x * y));
+    // quadrant
+    const bool swap = (k & 1) != 0;
+    double ss = swap ? c_ : s_;
+    double cc = swap ? s_ : c_;
+    sn = (k & 2) ? -ss : ss;
+    cs = ((k + 1) & 2) ? -cc : cc;
+}
+DEV void sincos_0_2pi(float phi, float& sn, float& cs) { ::sincosf(phi, &sn, &cs); }
 DEV double m_log(double x) { return ::log(x); }   DEV float m_log(float x) { return ::logf(x); }
 DEV double m_acos(double x) { return ::acos(x); } DEV float m_acos(float x) { return ::acosf(x); }
 DEV double m_atan2(double y, double x) { return ::atan2(y, x); } DEV float m_atan2(float y, float x) { return ::atan2f(y, x); }
@@ -100,15 +143,21 @@ template <typename T> DEV void set_face_normal(Rec<T>& rec, V3<T> dir, V3<T> out
 DEV void plane_axes(uint32_t plane, uint32_t& ki, uint32_t& ai, uint32_t& bi) {                                    // rect.rs:26-32
     ki = 2u - plane; ai = (plane == 2u) ? 1u : 0u; bi = (plane == 0u) ? 1u : 2u;
 }
-template <typename T> DEV bool rect_test(const DRect<T>& r, const RayT<T>& ray, T t_min, T t_max, T& t_out) {      // rect.rs:49-60
-    uint32_t ki, ai, bi; plane_axes(r.plane, ki, ai, bi);
-    T t = (r.k - get(ray.o, ki)) / get(ray.d, ki);
+template <typename T> DEV bool rect_test_axes(const DRect<T>& r, T ok, T dk, T oa, T da, T ob, T db, T t_min, T t_max, T& t_out) {   // rect.rs:49-60
+    T t = (r.k - ok) / dk;
     if (t < t_min || t > t_max) return false;
-    T a = get(ray.o, ai) + t * get(ray.d, ai);
-    T b = get(ray.o, bi) + t * get(ray.d, bi);
+    T a = oa + t * da;
+    T b = ob + t * db;
     if (a < r.a0 || a > r.a1 || b < r.b0 || b > r.b1) return false;
     t_out = t;
     return true;
+}
+// The axis triple (k,a,b) of rect.rs:26-32 is chosen by a branch on `plane` rather than by per-component selects:
+// at the top level `plane` is wave-uniform (a scalar branch); in BVH leaves (cube faces) it is uniform in practice.
+template <typename T> DEV bool rect_test(const DRect<T>& r, const RayT<T>& ray, T t_min, T t_max, T& t_out) {
+    if (r.plane == 2u) return rect_test_axes(r, ray.o.x, ray.d.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, t_max, t_out);   // YZ: k=x a=y b=z
+    if (r.plane == 1u) return rect_test_axes(r, ray.o.y, ray.d.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, t_max, t_out);   // XZ: k=y a=x b=z
+    return rect_test_axes(r, ray.o.z, ray.d.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, t_max, t_out);                      // XY: k=z a=x b=y
 }
 template <typename T> DEV bool sphere_test(V3<T> center, T radius, const RayT<T>& ray, T t_min, T t_max, T& t_out) {   // sphere.rs:56-74
     V3<T> oc = ray.o - center;
@@ -151,9 +200,19 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
     bool any = false;
     T closest = t_max;
     if (kind == G_RECT) {
+        // software-pipelined record fetch: record i+1 is requested before record i is tested (the table carries one
+        // padding record), so a scalar load's latency overlaps a whole rect test instead of stalling each iteration
+        DRect<T> cur = ld_rect(P.rects + first);
         for (uint32_t i = first; i < first + count; i++) {
+            // touch the current record first (its load was issued one iteration ago), THEN request the next one: the
+            // scalar-load wait lands before the new request instead of behind it
+            asm volatile("" :: "s"(cur.plane));
+            __builtin_amdgcn_sched_barrier(0);
+            const DRect<T> nxt = ld_rect(P.rects + i + 1);
+            __builtin_amdgcn_sched_barrier(0);
             T t;
-            if (rect_test(ld_rect(P.rects + i), ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
+            if (rect_test(cur, ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
+            cur = nxt;
         }
     } else if ((FEATS & F_SPHERES) && kind == G_SPHERE) {
         for (uint32_t i = first; i < first + count; i++) {
@@ -352,8 +411,11 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         if (op.kind == OP_TRANSLATE) {
             rec.p = rec.p + mk<T>(op.x, op.y, op.z);                                  // translate.rs:26
         } else if (op.kind == OP_ROTATE) {                                            // rotate.rs:90-104
-            RayT<T> rr = ray;                                                         // the ray this Rotate handed to its child
-            for (int q = 0; q <= k; q++) op_fwd(ld_op(P.ops + ob.first_op + (uint32_t)q), rr);
+            RayT<T> rr = r;                                                           // the ray this Rotate handed to its child:
+            if (k != (int)ob.n_ops - 1) {                                             // = r when the Rotate is innermost (usual)
+                rr = ray;
+                for (int q = 0; q <= k; q++) op_fwd(ld_op(P.ops + ob.first_op + (uint32_t)q), rr);
+            }
             rot_back(op.axis, op.x, op.y, rec.p);
             V3<T> nw = rec.n;
             rot_back(op.axis, op.x, op.y, nw);
@@ -450,7 +512,7 @@ template <typename T> DEV V3<T> random_cosine_direction(Rng& rng) {             
     T r2 = rng_u01(rng, T(0));
     T z = rsqrt_(T(1.0) - r2);
     T phi = T(2.0) * PI_T * r1;
-    T sn, cs; m_sincos(phi, sn, cs);
+    T sn, cs; sincos_0_2pi(phi, sn, cs);
     T x = cs * rsqrt_(r2);
     T y = sn * rsqrt_(r2);
     return mk<T>(x, y, z);
@@ -513,8 +575,9 @@ template <typename T, uint32_t FEATS> DEV V3<T> light_random(const KParams<T>& P
         T r2 = rng_u01(rng, T(0));
         T z = T(1.0) + r2 * (rsqrt_(T(1.0) - s.r * s.r / distance_squared) - T(1.0));
         T phi = T(2.0) * PI_T * r1;
-        T x = m_cos(phi) * rsqrt_(T(1.0) - z * z);
-        T y = m_sin(phi) * rsqrt_(T(1.0) - z * z);
+        T sn, cs; sincos_0_2pi(phi, sn, cs);
+        T x = cs * rsqrt_(T(1.0) - z * z);
+        T y = sn * rsqrt_(T(1.0) - z * z);
         return onb_local(uvw, mk<T>(x, y, z));
     }
     return mk<T>(T(1.0), T(0), T(0));                                                 // Hittable::random default, hit.rs:30
@@ -551,18 +614,33 @@ DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out,
 }
 
 // ------------------------------------------------------------------ the kernel
+static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-wave regeneration queue (sized for f64), 5120 B
+// RT_DIAG (diagnostic build only, never shipped): per-section wave-cycle shares via s_memtime, written to stats[3..8].
+#ifdef RT_DIAG
+#define DIAG_DECL unsigned long long dg_t = 0, dg_sum[6] = {0, 0, 0, 0, 0, 0};
+#define DIAG_T0() do { __builtin_amdgcn_sched_barrier(0); dg_t = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define DIAG_ADD(k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t1_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); dg_sum[k] += t1_ - dg_t; dg_t = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define DIAG_DECL
+#define DIAG_T0() do {} while (0)
+#define DIAG_ADD(k) do {} while (0)
+#endif
 template <typename T, uint32_t FEATS>
 __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(const KParams<T> P) {
-    extern __shared__ uint32_t lds_stack[];
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t* stack = lds_stack + (threadIdx.x >> 6) * (P.stack_depth * 64u) + lane;
+    // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    unsigned char* regen = lds_raw + wave_in_block * REGEN_BYTES;
+    T* q_real = (T*)regen;                                         // [7][64]: o.x o.y o.z d.x d.y d.z time
+    uint32_t* q_u32 = (uint32_t*)(regen + 7u * 64u * sizeof(T));   // [6][64]: rng s0..s3, local pixel, sample
+    uint32_t* stack = (uint32_t*)(lds_raw + 4u * REGEN_BYTES) + wave_in_block * (P.stack_depth * 64u) + lane;
 
     const uint32_t n_local_px = P.n_local_tiles * P.tile_px;
     const uint32_t n_px = P.W * P.H;
     const uint32_t NONE = 0xFFFFFFFFu;
 
-    // wave-uniform queue cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px.
-    // cur_gp / cur_i / cur_j: the cursor pixel's global index and image coordinates, recomputed (wave-uniform,
+    // wave-uniform work cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px (one dequeued
+    // chunk).  cur_gp / cur_i / cur_j: the cursor pixel's global index and image coordinates, recomputed (wave-uniform,
     // once per pixel, not per sample) whenever the cursor moves.
     uint32_t cur_px = 0, end_px = 0, cur_s = 0;
     uint32_t cur_gp = 0, cur_i = 0, cur_j = 0;
@@ -574,6 +652,10 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
         cur_i = cur_gp - row * P.W;
         cur_j = P.H - 1u - row;           // row 0 is j = H-1, main.rs:772
     };
+    // regeneration queue (wave-uniform): entries [q_head, q_head + q_count) of this wave's LDS queue hold camera paths
+    // that were generated 64 at a time with every lane busy; lanes whose path ended pop one instead of running the
+    // camera code themselves at ~1/3 lane occupancy.
+    uint32_t q_head = 0, q_count = 0;
 
     // per-lane path state
     bool alive = false;
@@ -586,71 +668,102 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
     double acc[3] = {0.0, 0.0, 0.0};
     uint32_t n_nonfinite = 0;
     unsigned long long n_iters = 0, n_active = 0;
+    DIAG_DECL
 
     for (;;) {
-        // ---- hand the next samples to lanes whose path has ended
+        DIAG_T0();
+        // ---- lanes whose path has ended take the next camera path from the wave's queue
         bool got_new = false;
-        uint32_t new_px = 0, new_s = 0, new_gp = 0, new_i = 0, new_j = 0;
+        uint32_t new_px = 0;
         for (;;) {
             unsigned long long want = __ballot(!alive && !got_new);
             if (want == 0) break;
-            if (cur_px == end_px) {
+            if (q_count == 0) {
+                // -- refill the queue: the next (up to) 64 samples of the cursor, all lanes generating (main.rs:813-820)
                 if (queue_done) break;
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(P.queue, 1u);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                if (c >= P.n_chunks) { queue_done = true; break; }
-                cur_px = c * P.chunk_px;
-                end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
-                cur_s = 0;
-                locate();
+                bool have = false;
+                uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
+                uint32_t n_gen = 0;
+                while (n_gen < 64u) {
+                    if (cur_px == end_px) {
+                        uint32_t c = 0;
+                        if (lane == 0) c = atomicAdd(P.queue, 1u);
+                        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                        if (c >= P.n_chunks) { queue_done = true; break; }
+                        cur_px = c * P.chunk_px;
+                        end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
+                        cur_s = 0;
+                        locate();
+                    }
+                    if (cur_gp >= n_px) { cur_px++; cur_s = 0; if (cur_px != end_px) locate(); continue; }   // padding pixel of the last tile
+                    uint32_t avail = P.spp - cur_s;
+                    uint32_t room = 64u - n_gen;
+                    uint32_t take = room < avail ? room : avail;
+                    if (lane >= n_gen && lane < n_gen + take) { have = true; g_px = cur_px; g_s = cur_s + (lane - n_gen); g_gp = cur_gp; g_i = cur_i; g_j = cur_j; }
+                    n_gen += take;
+                    cur_s += take;
+                    if (cur_s == P.spp) { cur_px++; cur_s = 0; if (cur_px != end_px) locate(); }
+                }
+                if (n_gen == 0) break;
+                if (have) {
+                    Rng g = rng_for_path(P.seed, g_gp, g_s);
+                    T random_u = rng_u01(g, T(0));
+                    T random_v = rng_u01(g, T(0));
+                    T u = (T(g_i) + random_u) / T(P.W - 1u);
+                    T v = (T(g_j) + random_v) / T(P.H - 1u);
+                    // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
+                    T da, db;
+                    for (;;) {
+                        da = rng_range(g, T(-1.0), T(1.0));
+                        db = rng_range(g, T(-1.0), T(1.0));
+                        V3<T> pd = mk<T>(da, db, T(0));
+                        if (dot(pd, pd) < T(1.0)) break;       // `p.length() < 1.0` (vec.rs:101): sqrt(x) < 1 <=> x < 1
+                    }
+                    V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
+                    V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
+                    T time = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
+                    V3<T> go = ld3(P.cam.origin) + offset;
+                    V3<T> gd = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
+                    q_real[0u * 64u + lane] = go.x; q_real[1u * 64u + lane] = go.y; q_real[2u * 64u + lane] = go.z;
+                    q_real[3u * 64u + lane] = gd.x; q_real[4u * 64u + lane] = gd.y; q_real[5u * 64u + lane] = gd.z;
+                    q_real[6u * 64u + lane] = time;
+                    q_u32[0u * 64u + lane] = g.s0; q_u32[1u * 64u + lane] = g.s1; q_u32[2u * 64u + lane] = g.s2; q_u32[3u * 64u + lane] = g.s3;
+                    q_u32[4u * 64u + lane] = g_px; q_u32[5u * 64u + lane] = g_s;
+                }
+                q_head = 0; q_count = n_gen;
+                __builtin_amdgcn_wave_barrier();          // one wave: LDS writes above are ordered before the reads below
             }
-            uint32_t avail = P.spp - cur_s;
             uint32_t n_want = (uint32_t)__popcll(want);
-            uint32_t take = n_want < avail ? n_want : avail;
+            uint32_t take = n_want < q_count ? n_want : q_count;
             uint32_t rank = lane_rank(want);
-            if (!alive && !got_new && rank < take) { got_new = true; new_px = cur_px; new_s = cur_s + rank; new_gp = cur_gp; new_i = cur_i; new_j = cur_j; }
-            cur_s += take;
-            if (cur_s == P.spp) { cur_px++; cur_s = 0; if (cur_px != end_px) locate(); }
+            if (!alive && !got_new && rank < take) {
+                const uint32_t e = q_head + rank;
+                got_new = true;
+                ray.o = mk<T>(q_real[0u * 64u + e], q_real[1u * 64u + e], q_real[2u * 64u + e]);
+                ray.d = mk<T>(q_real[3u * 64u + e], q_real[4u * 64u + e], q_real[5u * 64u + e]);
+                ray.tm = q_real[6u * 64u + e];
+                rng.s0 = q_u32[0u * 64u + e]; rng.s1 = q_u32[1u * 64u + e]; rng.s2 = q_u32[2u * 64u + e]; rng.s3 = q_u32[3u * 64u + e];
+                new_px = q_u32[4u * 64u + e]; path_s = q_u32[5u * 64u + e];
+            }
+            q_head += take; q_count -= take;
         }
         if (__ballot(alive || got_new) == 0) break;     // queue empty and every path finished
+        DIAG_ADD(0);
 
         // ---- lanes moving on to another pixel hand in their partial sum
         flush_acc(got_new && acc_px != NONE && acc_px != new_px, acc_px, acc, P.out, lane);
 
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
-            path_px = new_px; path_s = new_s;
-            const uint32_t gp = new_gp, i = new_i, j = new_j;
-            if (gp < n_px) {
-                rng = rng_for_path(P.seed, gp, new_s);
-                // main.rs:813-820
-                T random_u = rng_u01(rng, T(0));
-                T random_v = rng_u01(rng, T(0));
-                T u = (T(i) + random_u) / T(P.W - 1u);
-                T v = (T(j) + random_v) / T(P.H - 1u);
-                // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
-                T da, db;
-                for (;;) {
-                    da = rng_range(rng, T(-1.0), T(1.0));
-                    db = rng_range(rng, T(-1.0), T(1.0));
-                    V3<T> pd = mk<T>(da, db, T(0));
-                    if (dot(pd, pd) < T(1.0)) break;       // `p.length() < 1.0` (vec.rs:101): sqrt(x) < 1 <=> x < 1
-                }
-                V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
-                V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
-                T time = P.cam.time0 + rng_u01(rng, T(0)) * (P.cam.time1 - P.cam.time0);
-                ray.o = ld3(P.cam.origin) + offset;
-                ray.d = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
-                ray.tm = time;
-                beta = mk<T>(T(1.0), T(1.0), T(1.0));
-                depth_left = P.max_depth;
-                alive = true;
-            }
+            path_px = new_px;
+            beta = mk<T>(T(1.0), T(1.0), T(1.0));
+            depth_left = P.max_depth;
+            alive = true;
         }
 
         n_iters++;
         if (alive) n_active++;
+        DIAG_ADD(1);
 
         // ---- one level of ray_color (main.rs:41-120) for every live lane
         if (alive) {
@@ -660,12 +773,15 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
                 done = true;                            // main.rs:42-45
             } else {
                 T t_hit; HitId id; id.obj = 0; id.prim = 0;
-                if (!world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack)) {       // main.rs:48
+                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
+                DIAG_ADD(2);
+                if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
                 } else {
                     // material of the hit decides whether (u,v) are needed at all
                     Rec<T> rec;
                     finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
+                    DIAG_ADD(3);
                     const DMaterial<T> mt = ld_mat(P.materials + rec.mat);
                     if (mt.kind == M_LAMBERTIAN) {                                          // mat.rs:225-249, main.rs:92-98
                         V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
@@ -734,6 +850,7 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
                     }
                 }
             }
+            DIAG_ADD(4);
             if (done) {
                 V3<T> L = beta * e;
                 double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
@@ -745,6 +862,7 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
                 }
                 alive = false;
             }
+            DIAG_ADD(5);
         }
     }
     // ---- the queue is empty: hand in what is left
@@ -755,6 +873,9 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
         if (lane == 0) { atomicAdd(&P.stats[1], n_iters); atomicAdd(&P.stats[2], a); }
+#ifdef RT_DIAG
+        if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.stats[3 + k], dg_sum[k]);
+#endif
     }
 }
 
