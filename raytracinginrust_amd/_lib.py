@@ -24,7 +24,7 @@ def load() -> Backend:
     global _backend
     if _backend is not None:
         return _backend
-    _backend = load_path(LIB_PATH)
+    _backend = load_path(os.environ.get("RT_AMD_LIB", LIB_PATH))     # RT_AMD_LIB: developer override (tools/)
     return _backend
 
 

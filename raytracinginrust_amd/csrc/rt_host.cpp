@@ -349,8 +349,12 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     uint64_t n_local_px = (uint64_t)P.n_local_tiles * tile_px;
     if (n_local_px >= 0xFFFFFFFFull) return set_err("too many local pixels");
     if ((size_t)n_local_px * 3 * sizeof(double) > d_out_bytes) return set_err("output buffer too small for n_local_tiles * tile_px * 3 doubles");
-    P.chunk_px = spp >= 256 ? 1u : (256u + spp - 1) / spp;
-    P.n_chunks = (uint32_t)((n_local_px + P.chunk_px - 1) / P.chunk_px);
+    // work chunks of about 256 samples: several pixels per chunk at low spp, several chunks per pixel at high spp
+    // (a fine grain keeps the end-of-frame tail short when the frame is split over many GPUs)
+    const uint32_t CH = 256u;
+    if (spp >= 2u * CH) { P.chunk_px = 1u; P.chunks_per_px = (spp + CH - 1) / CH; P.chunk_spp = (spp + P.chunks_per_px - 1) / P.chunks_per_px; }
+    else { P.chunk_px = (CH + spp - 1) / spp; P.chunks_per_px = 1u; P.chunk_spp = spp; }
+    P.n_coarse_px = 0;
     if (!s.d_queue) HIP_OK(hipMalloc(&s.d_queue, 64));
     if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 128));
     if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
@@ -368,6 +372,15 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     uint64_t n_blocks = (uint64_t)prop.multiProcessorCount * (uint64_t)bpc;
     if (n_blocks > blocks_needed) n_blocks = blocks_needed;
     if (n_blocks == 0) n_blocks = 1;
+    {   // split only the last ~1.5 pixels per resident wave into fine chunks
+        uint64_t fine_px = n_blocks * 4ull * 3ull / 2ull;
+        if (P.chunks_per_px > 1 && n_local_px > fine_px) P.n_coarse_px = (uint32_t)(n_local_px - fine_px);
+        uint64_t n_chunks64 = P.chunks_per_px > 1
+            ? (uint64_t)P.n_coarse_px + (n_local_px - P.n_coarse_px) * (uint64_t)P.chunks_per_px
+            : (n_local_px + P.chunk_px - 1) / P.chunk_px;
+        if (n_chunks64 >= 0xFFFFFFFFull) return set_err("too many work chunks");
+        P.n_chunks = (uint32_t)n_chunks64;
+    }
 
     HIP_OK(hipMemsetAsync(s.d_queue, 0, 64, stream));
     HIP_OK(hipMemsetAsync(s.d_stats, 0, 128, stream));

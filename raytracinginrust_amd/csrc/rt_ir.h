@@ -83,7 +83,11 @@ template <typename T> struct KParams {
     uint32_t flags;
     // work decomposition: this launch owns tiles t = rank + q*world, q in [0, n_local_tiles)
     uint32_t tile_px, rank, world, n_local_tiles;
-    uint32_t chunk_px, n_chunks;   // dequeue unit over the local pixel space
+    // dequeue unit: chunk c covers samples [sub*chunk_spp, ..) of chunk_px consecutive local pixels starting at
+    // (c / chunks_per_px) * chunk_px, sub = c % chunks_per_px.  Either chunks_per_px == 1 (whole pixels) or chunk_px == 1.
+    // With chunk_px == 1 the first n_coarse_px pixels are whole-pixel chunks and only the rest are split (guided
+    // self-scheduling: fine chunks where they shorten the end-of-frame tail, coarse ones elsewhere).
+    uint32_t chunk_px, chunks_per_px, chunk_spp, n_coarse_px, n_chunks;
     uint32_t* queue;               // zeroed before launch
     double* out;                   // n_local_tiles * tile_px * 3 (always f64: per-pixel sums)
     double* samples_out;           // optional: local_px * spp * 3

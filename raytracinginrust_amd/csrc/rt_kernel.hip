@@ -594,7 +594,8 @@ DEV double wave_sum(double x) {                      // fixed butterfly: determi
 }
 
 // Lanes with `need` set hold a partial per-pixel sum (acc) for local pixel acc_px.  All partials of one pixel are
-// combined by a masked butterfly and added to out[] by one lane; the owning wave is the only writer of a pixel.
+// combined by a masked butterfly and added to out[] by one lane with one f64 atomic per channel (a handful per pixel
+// per frame: this is the kernel's only global write traffic).
 DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out, uint32_t lane) {
     unsigned long long m = __ballot(need);
     while (m) {
@@ -605,8 +606,8 @@ DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out,
         double s1 = wave_sum(mine ? acc[1] : 0.0);
         double s2 = wave_sum(mine ? acc[2] : 0.0);
         if (lane == leader) {
-            double* o = out + (size_t)px * 3u;
-            o[0] += s0; o[1] += s1; o[2] += s2;
+            double* o = out + (size_t)px * 3u;        // hardware f64 atomics: a pixel's samples may be split over several waves
+            unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2);
         }
         need = need && !mine;
         m = __ballot(need);
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
     // wave-uniform work cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px (one dequeued
     // chunk).  cur_gp / cur_i / cur_j: the cursor pixel's global index and image coordinates, recomputed (wave-uniform,
     // once per pixel, not per sample) whenever the cursor moves.
-    uint32_t cur_px = 0, end_px = 0, cur_s = 0;
+    uint32_t cur_px = 0, end_px = 0, cur_s = 0, s_lo = 0, s_hi = 0;      // the chunk's sample range per pixel is [s_lo, s_hi)
     uint32_t cur_gp = 0, cur_i = 0, cur_j = 0;
     bool queue_done = false;
     auto locate = [&]() {                 // local pixel -> global output-order pixel (tile t = rank + q * world)
@@ -690,19 +691,27 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
                         if (lane == 0) c = atomicAdd(P.queue, 1u);
                         c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                         if (c >= P.n_chunks) { queue_done = true; break; }
-                        cur_px = c * P.chunk_px;
-                        end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
-                        cur_s = 0;
+                        if (c < P.n_coarse_px) {                      // a whole pixel
+                            cur_px = c; end_px = c + 1u; s_lo = 0u; s_hi = P.spp;
+                        } else {
+                            const uint32_t c2 = c - P.n_coarse_px;
+                            const uint32_t cp = c2 / P.chunks_per_px, sub = c2 - cp * P.chunks_per_px;
+                            cur_px = P.n_coarse_px + cp * P.chunk_px;
+                            end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
+                            s_lo = sub * P.chunk_spp;
+                            s_hi = s_lo + P.chunk_spp; if (s_hi > P.spp) s_hi = P.spp;
+                        }
+                        cur_s = s_lo;
                         locate();
                     }
-                    if (cur_gp >= n_px) { cur_px++; cur_s = 0; if (cur_px != end_px) locate(); continue; }   // padding pixel of the last tile
-                    uint32_t avail = P.spp - cur_s;
+                    if (cur_gp >= n_px || s_lo >= s_hi) { cur_px++; cur_s = s_lo; if (cur_px != end_px) locate(); continue; }   // padding pixel / empty range
+                    uint32_t avail = s_hi - cur_s;
                     uint32_t room = 64u - n_gen;
                     uint32_t take = room < avail ? room : avail;
                     if (lane >= n_gen && lane < n_gen + take) { have = true; g_px = cur_px; g_s = cur_s + (lane - n_gen); g_gp = cur_gp; g_i = cur_i; g_j = cur_j; }
                     n_gen += take;
                     cur_s += take;
-                    if (cur_s == P.spp) { cur_px++; cur_s = 0; if (cur_px != end_px) locate(); }
+                    if (cur_s == s_hi) { cur_px++; cur_s = s_lo; if (cur_px != end_px) locate(); }
                 }
                 if (n_gen == 0) break;
                 if (have) {
