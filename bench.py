@@ -31,7 +31,7 @@ def cpu_baseline(w, sample_spp):
     from raytracinginrust_amd import workloads
     be = orc.load()
     b, cam, bg = workloads.build(w, be)
-    threads = orc.hardware_threads()
+    threads = min(orc.hardware_threads(), len(os.sched_getaffinity(0)))      # the cores this process may actually use
     t = time.perf_counter()
     _, cnt = orc.render(b, cam, bg, w.W, w.H, sample_spp, w.max_depth, want_counters=True, nthreads=threads, mode=0)
     dt = time.perf_counter() - t
