@@ -82,6 +82,13 @@ struct Metal { static Material new_(Scene& s, Color albedo, double fuzz) { retur
 struct Dielectric { static Material new_(Scene& s, double ir) { return {s.chk(rt_material_dielectric(s.raw(), ir))}; } };
 struct DiffuseLight { static Material new_(Scene& s, Texture emit) { return {s.chk(rt_material_diffuse_light(s.raw(), emit.id))}; } };
 struct Isotropic { static Material new_(Scene& s, Texture albedo) { return {s.chk(rt_material_isotropic(s.raw(), albedo.id))}; } };
+struct PBR {                                            // src/mat.rs:101
+    static Material new_(Scene& s, Texture base_color, double metallic, double subsurface, double specular, double roughness, double specular_tint,
+                         double anisotropic, double sheen, double sheen_tint, double clearcoat, double clearcoat_gloss) {
+        const double p[10] = {metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss};
+        return {s.chk(rt_material_pbr(s.raw(), base_color.id, p))};
+    }
+};
 
 // ---- hittables
 struct Sphere { static Hittable new_(Scene& s, Point3 c, double r, Material m) { return {s.chk(rt_sphere(s.raw(), c.e, r, m.id))}; } };

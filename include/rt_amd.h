@@ -69,12 +69,15 @@ int rt_texture_check(rt_scene*, int odd, int even);                   /* CheckTe
 int rt_texture_noise(rt_scene*, double scale, rt_rng* rng);           /* NoiseTexture::new (Perlin::new draws from rng, src/perlin.rs:67-75) */
 int rt_texture_image(rt_scene*, const uint8_t* rgb8, uint32_t width, uint32_t height);   /* ImageTexture::new */
 
-/* materials, src/mat.rs:205,260,303,383,410 */
+/* materials, src/mat.rs:101,205,260,303,383,410 */
 int rt_material_lambertian(rt_scene*, int texture);
 int rt_material_metal(rt_scene*, const double albedo[3], double fuzz);
 int rt_material_dielectric(rt_scene*, double index_of_refraction);
 int rt_material_diffuse_light(rt_scene*, int texture);
 int rt_material_isotropic(rt_scene*, int texture);
+/* PBR::new (the principled "Disney" material), src/mat.rs:101: params = metallic, subsurface, specular, roughness,
+ * specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss (the constructor's argument order) */
+int rt_material_pbr(rt_scene*, int base_color_texture, const double params[10]);
 
 /* hittables */
 int rt_sphere(rt_scene*, const double center[3], double radius, int material);                         /* Sphere::new, src/sphere.rs:46        */

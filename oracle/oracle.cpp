@@ -23,6 +23,9 @@
 // which tests/test_oracle_kat.py checks.  Beyond that the oracle is pinned by closed-form
 // KATs and estimator invariants (tests/test_oracle_*.py), not by the reference itself.
 //
+// Also restated: the principled ("Disney") material PBR + PDF::BRDF + the Microfacet arm of ray_color (mat.rs:10-52,84-197,
+// pdf.rs:20-60,97-130,151-160, main.rs:99-105), which no reference scene attaches to an object.
+//
 // Stated deviations from the reference (all forced):
 //   D1  RNG: one xoshiro128++ stream per (seed, pixel, sample) (oracle/orc_rng.h) instead
 //       of thread_rng(); draw kinds/order follow SURVEY.md Appendix A.
@@ -392,16 +395,100 @@ static Vec3 random_cosine_direction(Sampler& s) {                      // pdf.rs
     double y = std::sin(phi) * std::sqrt(r2);
     return Vec3(x, y, z);
 }
+// mat.rs:10-52 helpers of the principled ("Disney") material
+static inline double mixf(double a, double b, double t) { return a * (1.0 - t) + b * t; }                      // mat.rs:50-52
+static inline Vec3 mixv(const Vec3& a, const Vec3& b, double t) {                                              // vec.rs:60-68
+    return Vec3(a[0] * (1.0 - t) + b[0] * t, a[1] * (1.0 - t) + b[1] * t, a[2] * (1.0 - t) + b[2] * t);
+}
+static inline double schlick_fresnel(double u) { double m = f_clamp(1.0 - u, 0.0, 1.0); double m2 = m * m; return m2 * m2 * m; }   // mat.rs:10-14
+static inline double GTR_1(double n_dot_h, double a) {                                                          // mat.rs:16-24 (log2, as written)
+    if (a >= 1.0) return 1.0 / PI;
+    double a2 = a * a;
+    double t = 1.0 + (a2 - 1.0) * n_dot_h * n_dot_h;
+    return (a2 - 1.0) / (PI * std::log2(a2) * t);
+}
+static inline double GTR_2_aniso(double n_dot_h, double h_dot_x, double h_dot_y, double ax, double ay) {        // mat.rs:32-34
+    double p = h_dot_x / ax, q = h_dot_y / ay;
+    double s = p * p + q * q + n_dot_h * n_dot_h;
+    return 1.0 / (PI * ax * ay * (s * s));
+}
+static inline double smithG_GGX(double n_dot_v, double alphaG) {                                                // mat.rs:36-40
+    double a = alphaG * alphaG, b = n_dot_v * n_dot_v;
+    return 1.0 / (n_dot_v + std::sqrt(a + b - a * b));
+}
+static inline double smithG_GGX_aniso(double n_dot_v, double v_dot_x, double v_dot_y, double ax, double ay) {   // mat.rs:42-44
+    double p = v_dot_x * ax, q = v_dot_y * ay;
+    return 1.0 / (n_dot_v + std::sqrt(p * p + q * q + n_dot_v * n_dot_v));
+}
+static inline Vec3 mon_to_lin(const Vec3& x) { return Vec3(std::pow(x.x(), 2.2), std::pow(x.y(), 2.2), std::pow(x.z(), 2.2)); }   // mat.rs:46-48
+static inline Vec3 spherical_direction(double sin_theta, double cos_theta, double sin_phi, double cos_phi) {    // pdf.rs:20-22
+    return Vec3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+}
+static Vec3 GTR_1_direction(const Vec3& r_in, double clearcoat_gloss, Sampler& s) {                             // pdf.rs:24-36
+    double r1 = s.rng.range(0.0, 1.0);
+    double r2 = s.rng.range(0.0, 1.0);
+    double a = mixf(0.1, 0.001, clearcoat_gloss);
+    double a2 = a * a;
+    double cos_theta = std::sqrt(f_max(0.001, (1.0 - std::pow(a2, 1.0 - r1)) / (1.0 - a2)));
+    double sin_theta = std::sqrt(f_max(0.001, 1.0 - cos_theta * cos_theta));
+    double phi = PI * 2.0 * r2;
+    Vec3 wh = spherical_direction(sin_theta, cos_theta, std::sin(phi), std::cos(phi));
+    return r_in.reflect(wh);
+}
+static Vec3 GTR_2_aniso_direction(const Vec3& r_in, double roughness, double anisotropic, Sampler& s) {         // pdf.rs:38-60
+    double r1 = s.rng.range(0.0, 1.0);
+    double r2 = s.rng.range(0.0, 1.0);
+    double aspect = std::sqrt(1.0 - anisotropic * 0.9);
+    double ax = f_max(roughness * roughness / aspect, 0.001);
+    double ay = f_max(roughness * roughness * aspect, 0.001);
+    double phi = std::atan(ay / ax * std::tan(2.0 * PI * r2 + 0.5 * PI));
+    if (r2 > 0.5) phi += PI;
+    double sin_phi = std::sin(phi);
+    double cos_phi = std::cos(phi);
+    double ax_2 = ax * ax;
+    double ay_2 = ay * ay;
+    double a2 = 1.0 / (cos_phi * cos_phi / ax_2 + sin_phi * sin_phi / ay_2);
+    double tan_theta_2 = a2 * r1 / (1.0 - r1);
+    double cos_theta = 1.0 / std::sqrt(1.0 + tan_theta_2);
+    double sin_theta = std::sqrt(f_max(0.001, 1.0 - cos_theta * cos_theta));
+    Vec3 wh = spherical_direction(sin_theta, cos_theta, std::sin(phi), std::cos(phi));
+    return r_in.reflect(wh);
+}
+
 struct PDF {                                                           // pdf.rs:62-67
-    enum Kind { Cosine, HittableK, Mixture } kind;
-    ONB uvw;                                  // Cosine
+    enum Kind { Cosine, HittableK, Mixture, BRDF } kind;
+    ONB uvw;                                  // Cosine, BRDF
     Point3 origin; const Hittable* hittable;  // Hittable
     const PDF* p0; const PDF* p1;             // Mixture
+    Vec3 r_in; double roughness = 0, anisotropic = 0, clearcoat = 0, clearcoat_gloss = 0;   // BRDF
+    static PDF brdf_pdf(const Vec3& w, const Vec3& r_in, double roughness, double anisotropic, double clearcoat, double clearcoat_gloss) {   // pdf.rs:70-79
+        PDF p; p.kind = BRDF; p.uvw = ONB::build_from_w(w); p.hittable = nullptr; p.p0 = p.p1 = nullptr;
+        p.r_in = r_in; p.roughness = roughness; p.anisotropic = anisotropic; p.clearcoat = clearcoat; p.clearcoat_gloss = clearcoat_gloss;
+        return p;
+    }
     static PDF cosine_pdf(const Vec3& w) { PDF p; p.kind = Cosine; p.uvw = ONB::build_from_w(w); p.hittable = nullptr; p.p0 = p.p1 = nullptr; return p; }   // pdf.rs:81-85
     static PDF hittable_pdf(const Point3& o, const Hittable* h) { PDF p; p.kind = HittableK; p.origin = o; p.hittable = h; p.p0 = p.p1 = nullptr; return p; }   // pdf.rs:87-89
     static PDF mixture_pdf(const PDF* a, const PDF* b) { PDF p; p.kind = Mixture; p.hittable = nullptr; p.p0 = a; p.p1 = b; return p; }                        // pdf.rs:91-93
     double value(const Vec3& r_out, Sampler& s) const {                // pdf.rs:95-147
         switch (kind) {
+        case BRDF: {                                                   // pdf.rs:97-130
+            double cosine = r_out.normalized().dot(uvw.w());
+            if (cosine <= 0.0) return 0.0;
+            double diffuse_pdf = cosine / PI;
+            Vec3 l = r_in.normalized() * (-1.0);
+            Vec3 v = r_out.normalized();
+            Vec3 n = uvw.w(), x = uvw.u(), y = uvw.v();
+            double n_dot_l = n.dot(l);
+            Vec3 h = (l + v).normalized();
+            double n_dot_h = n.dot(h);
+            if (n_dot_h <= 0.0) return 0.0;
+            double aspect = std::sqrt(1.0 - anisotropic * 0.9);
+            double ax = f_max(roughness * roughness / aspect, 0.001);
+            double ay = f_max(roughness * roughness * aspect, 0.001);
+            double specular_pdf = GTR_2_aniso(n_dot_h, h.dot(x), h.dot(y), ax, ay) * std::fabs(n_dot_h) * 0.25 / n_dot_l;
+            double clearcoat_pdf = GTR_1(n_dot_h, mixf(0.1, 0.001, clearcoat_gloss)) * std::fabs(n_dot_h) * 0.25 / n_dot_l;
+            return (diffuse_pdf + specular_pdf + clearcoat_pdf) / 3.0;
+        }
         case Cosine: {
             double cosine = r_out.normalized().dot(uvw.w());
             return (cosine > 0.0) ? cosine / PI : 0.0;
@@ -412,6 +499,12 @@ struct PDF {                                                           // pdf.rs
     }
     Vec3 generate(Sampler& s) const {                                  // pdf.rs:149-176
         switch (kind) {
+        case BRDF: {                                                   // pdf.rs:151-160
+            double r = s.rng.range(0.0, 1.0);
+            if (r < 0.333) return uvw.local(random_cosine_direction(s));
+            if (r < 0.666) return uvw.local(GTR_1_direction(r_in, clearcoat_gloss, s));
+            return uvw.local(GTR_2_aniso_direction(r_in, roughness, anisotropic, s));
+        }
         case Cosine: return uvw.local(random_cosine_direction(s));
         case HittableK: return hittable->random(origin, s);
         default: return s.rng.boolean() ? p0->generate(s) : p1->generate(s);
@@ -420,8 +513,8 @@ struct PDF {                                                           // pdf.rs
 };
 
 // ---------------------------------------------------------------- src/mat.rs (Lambertian, Metal, Dielectric, DiffuseLight, Isotropic)
-struct ScatterRecord {                                                 // mat.rs:79-83 (Microfacet arm: PBR, out of scope)
-    enum Kind { Specular, Scatter } kind;
+struct ScatterRecord {                                                 // mat.rs:79-83
+    enum Kind { Specular, Scatter, Microfacet } kind;
     Ray specular_ray; Color attenuation; PDF pdf;
 };
 struct Material {                                                      // mat.rs:54-77
@@ -429,6 +522,55 @@ struct Material {                                                      // mat.rs
     virtual bool scatter_mc_method(const Ray&, const HitRecord&, Sampler&, ScatterRecord&) const { return false; }
     virtual double scattering_pdf(const Ray&, const HitRecord&, const Ray&) const { return 0.0; }
     virtual Color emitted(const HitRecord&, Sampler&) const { return Color(0.0, 0.0, 0.0); }
+    virtual Vec3 brdf(const Ray&, const Ray&, const HitRecord&, Sampler&) const { return Vec3(0.0, 0.0, 0.0); }   // mat.rs:74-76
+};
+struct PBR : Material {                                                // mat.rs:84-197 (Disney principled BRDF)
+    const Texture* base_color;
+    double metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss;
+    PBR(const Texture* t, const double* p) : base_color(t), metallic(p[0]), subsurface(p[1]), specular(p[2]), roughness(p[3]), specular_tint(p[4]),
+        anisotropic(p[5]), sheen(p[6]), sheen_tint(p[7]), clearcoat(p[8]), clearcoat_gloss(p[9]) {}
+    bool scatter_mc_method(const Ray& r_in, const HitRecord& rec, Sampler&, ScatterRecord& out) const override {   // mat.rs:118-131
+        out.kind = ScatterRecord::Microfacet;
+        out.pdf = PDF::brdf_pdf(rec.normal, r_in.direction(), roughness, anisotropic, clearcoat, clearcoat_gloss);
+        return true;
+    }
+    Vec3 brdf(const Ray& r_in, const Ray& r_out, const HitRecord& rec, Sampler& s) const override {                // mat.rs:133-195
+        Vec3 l = r_in.direction().normalized() * (-1.0);
+        Vec3 v = r_out.direction().normalized();
+        ONB onb = ONB::build_from_w(rec.normal);
+        Vec3 n = onb.w(), x = onb.u(), y = onb.v();
+        double n_dot_v = n.dot(v);
+        double n_dot_l = n.dot(l);
+        if (n_dot_l < 0.0 || n_dot_v < 0.0) return Vec3(0.0, 0.0, 0.0);
+        Vec3 h = (l + v).normalized();
+        double n_dot_h = n.dot(h);
+        double l_dot_h = l.dot(h);
+        Vec3 cd_lin = mon_to_lin(base_color->mapping(rec.u, rec.v, rec.position, s));
+        double cd_lum = 0.3 * cd_lin.x() + 0.6 * cd_lin.y() + 0.1 * cd_lin.z();
+        Vec3 c_tint = (cd_lum > 0.0) ? cd_lin / cd_lum : Vec3(1.0, 1.0, 1.0);
+        Vec3 c_spec0 = mixv(mixv(Vec3(1.0, 1.0, 1.0), c_tint, specular_tint) * 0.08 * specular, cd_lin, metallic);
+        Vec3 c_sheen = mixv(Vec3(1.0, 1.0, 1.0), c_tint, sheen_tint);
+        double fresnel_l = schlick_fresnel(n_dot_l);
+        double fresnel_v = schlick_fresnel(n_dot_v);
+        double fresnel_diffuse_90 = 0.5 + 2.0 * l_dot_h * l_dot_h * roughness;
+        double fresnel_diffuse = mixf(1.0, fresnel_diffuse_90, fresnel_l) * mixf(1.0, fresnel_diffuse_90, fresnel_v);
+        double fresnel_subface_scatter_90 = l_dot_h * l_dot_h * roughness;
+        double fresnel_subface_scatter = mixf(1.0, fresnel_subface_scatter_90, fresnel_l) * mixf(1.0, fresnel_subface_scatter_90, fresnel_v);
+        double subface_scatter = 1.25 * (fresnel_subface_scatter * (1.0 / (n_dot_l + n_dot_v) - 0.5) + 0.5);
+        double aspect = std::sqrt(1.0 - anisotropic * 0.9);
+        double ax = f_max(roughness * roughness / aspect, 0.001);
+        double ay = f_max(roughness * roughness * aspect, 0.001);
+        double d_specular = GTR_2_aniso(n_dot_h, h.dot(x), h.dot(y), ax, ay);
+        double fresnel_h = schlick_fresnel(l_dot_h);
+        Vec3 f_specular = mixv(c_spec0, Vec3(1.0, 1.0, 1.0), fresnel_h);
+        double g_specular = smithG_GGX_aniso(n_dot_l, l.dot(x), l.dot(y), ax, ay) * smithG_GGX_aniso(n_dot_v, v.dot(x), v.dot(y), ax, ay);
+        Vec3 fresnel_sheen = fresnel_h * sheen * c_sheen;
+        double d_reflect = GTR_1(n_dot_h, mixf(0.1, 0.001, clearcoat_gloss));
+        double f_reflect = mixf(0.04, 1.0, fresnel_h);
+        double g_reflect = smithG_GGX(n_dot_l, 0.25) * smithG_GGX(n_dot_v, 0.25);
+        return ((1.0 / PI) * mixf(fresnel_diffuse, subface_scatter, subsurface) * cd_lin + fresnel_sheen) * (1.0 - metallic)
+               + g_specular * f_specular * d_specular + Vec3(0.25, 0.25, 0.25) * clearcoat * g_reflect * f_reflect * d_reflect;
+    }
 };
 struct Lambertian : Material {                                         // mat.rs:200-250
     const Texture* albedo;
@@ -896,7 +1038,7 @@ static Color ray_color(const Ray& ray, const Color& background, const Hittable* 
             if (srec.kind == ScatterRecord::Specular) {                                              // main.rs:89-91
                 return srec.attenuation * ray_color(srec.specular_ray, background, world, lights, depth - 1, s);
             }
-            // ScatterRecord::Scatter, main.rs:92-98
+            // ScatterRecord::Scatter, main.rs:92-98; ScatterRecord::Microfacet, main.rs:99-105 (same sampling, brdf() weight)
             Vec3 dir; double pdf_value;
             if (lights->list.empty()) {                                                              // deviation D2
                 dir = srec.pdf.generate(s);
@@ -908,6 +1050,8 @@ static Color ray_color(const Ray& ray, const Color& background, const Hittable* 
                 pdf_value = mixture_pdf.value(dir, s);
             }
             Ray scattered(rec.position, dir, ray.time());
+            if (srec.kind == ScatterRecord::Microfacet)
+                return emitted + rec.material->brdf(ray, scattered, rec, s) * ray_color(scattered, background, world, lights, depth - 1, s) / pdf_value;
             return emitted + srec.attenuation * rec.material->scattering_pdf(ray, rec, scattered) *
                                  ray_color(scattered, background, world, lights, depth - 1, s) / pdf_value;
         }
@@ -979,6 +1123,7 @@ int orc_material_metal(void* s, const double* albedo, double fuzz) { return SC->
 int orc_material_dielectric(void* s, double ir) { return SC->add(new Dielectric(ir)); }
 int orc_material_diffuse_light(void* s, int tex) { return SC->add(new DiffuseLight(SC->textures[tex].get())); }
 int orc_material_isotropic(void* s, int tex) { return SC->add(new Isotropic(SC->textures[tex].get())); }
+int orc_material_pbr(void* s, int tex, const double* params10) { return SC->add(new PBR(SC->textures[tex].get(), params10)); }
 
 #define MAT(m) (SC->materials[m].get())
 #define HIT(h) (SC->hittables[h].get())
@@ -1136,6 +1281,23 @@ void orc_cosine_generate(const double* n, void* rng, double* out3) { PDF p = PDF
 double orc_cosine_value(const double* n, const double* dir) { Sampler tmp; PDF p = PDF::cosine_pdf(V(n)); return p.value(V(dir), tmp); }
 void orc_texture_value(void* s, int tex, double u, double v, const double* p, double* out3) { Sampler tmp; Color c = SC->textures[tex]->mapping(u, v, V(p), tmp); for (int i = 0; i < 3; i++) out3[i] = c[i]; }
 int orc_bounding_box(void* s, int h, double t0, double t1, double* out6) { AABB b; if (!HIT(h)->bounding_box(t0, t1, b)) return 0; for (int i = 0; i < 3; i++) { out6[i] = b.min[i]; out6[3 + i] = b.max[i]; } return 1; }
+// Material::brdf (mat.rs:133-195) and PDF::BRDF value/generate (pdf.rs:97-130,151-160) of a PBR material handle
+void orc_brdf(void* s, int mat, const double* r_in, const double* r_out, const double* normal, double* out3) {
+    Sampler tmp; HitRecord rec; rec.normal = V(normal); rec.position = Vec3(0, 0, 0);
+    Vec3 f = MAT(mat)->brdf(Ray(Vec3(0, 0, 0), V(r_in), 0.0), Ray(Vec3(0, 0, 0), V(r_out), 0.0), rec, tmp);
+    for (int i = 0; i < 3; i++) out3[i] = f[i];
+}
+double orc_brdf_pdf_value(void* s, int mat, const double* r_in, const double* r_out, const double* normal) {
+    Sampler tmp; HitRecord rec; rec.normal = V(normal); ScatterRecord sr;
+    MAT(mat)->scatter_mc_method(Ray(Vec3(0, 0, 0), V(r_in), 0.0), rec, tmp, sr);
+    return sr.pdf.value(V(r_out), tmp);
+}
+void orc_brdf_pdf_generate(void* s, int mat, const double* r_in, const double* normal, void* rng, double* out3) {
+    HitRecord rec; rec.normal = V(normal); ScatterRecord sr;
+    MAT(mat)->scatter_mc_method(Ray(Vec3(0, 0, 0), V(r_in), 0.0), rec, *(Sampler*)rng, sr);
+    Vec3 d = sr.pdf.generate(*(Sampler*)rng);
+    for (int i = 0; i < 3; i++) out3[i] = d[i];
+}
 // one camera ray: consumes the same draws as main.rs:813-820; out = origin(3) dir(3) time
 void orc_camera_ray(const orc_camera* c, uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint64_t seed, uint32_t s_idx, double* out7) {
     Camera cam = make_camera(c);

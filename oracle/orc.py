@@ -75,6 +75,10 @@ def load() -> Backend:
     lib.orc_bounding_box.restype = C.c_int
     lib.orc_bounding_box.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, d3]
     lib.orc_camera_ray.argtypes = [cam_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, d3]
+    lib.orc_brdf.argtypes = [C.c_void_p, C.c_int, d3, d3, d3, d3]
+    lib.orc_brdf_pdf_value.restype = C.c_double
+    lib.orc_brdf_pdf_value.argtypes = [C.c_void_p, C.c_int, d3, d3, d3]
+    lib.orc_brdf_pdf_generate.argtypes = [C.c_void_p, C.c_int, d3, d3, C.c_void_p, d3]
     lib.orc_ray_color.argtypes = [C.c_void_p, d3, d3, C.c_double, d3, C.c_uint64, C.c_void_p, d3]
     _backend = be
     return be
@@ -145,3 +149,15 @@ def random(b, h, o, rng):
 
 def ray_color(b, o, d, time_, background, depth, rng):
     out = _d(0, 0, 0); load().lib.orc_ray_color(b.h, _d(*o), _d(*d), time_, _d(*background), depth, rng.h, out); return list(out)
+
+
+def brdf(b, mat, r_in, r_out, normal):
+    out = _d(0, 0, 0); load().lib.orc_brdf(b.h, mat.id, _d(*r_in), _d(*r_out), _d(*normal), out); return list(out)
+
+
+def brdf_pdf_value(b, mat, r_in, r_out, normal):
+    return load().lib.orc_brdf_pdf_value(b.h, mat.id, _d(*r_in), _d(*r_out), _d(*normal))
+
+
+def brdf_pdf_generate(b, mat, r_in, normal, rng):
+    out = _d(0, 0, 0); load().lib.orc_brdf_pdf_generate(b.h, mat.id, _d(*r_in), _d(*normal), rng.h, out); return list(out)

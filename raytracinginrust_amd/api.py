@@ -74,6 +74,7 @@ class Backend:
         "material_dielectric": (C.c_int, [C.c_void_p, C.c_double]),
         "material_diffuse_light": (C.c_int, [C.c_void_p, C.c_int]),
         "material_isotropic": (C.c_int, [C.c_void_p, C.c_int]),
+        "material_pbr": (C.c_int, [C.c_void_p, C.c_int, c_double_p]),
         "sphere": (C.c_int, [C.c_void_p, c_double_p, C.c_double, C.c_int]),
         "moving_sphere": (C.c_int, [C.c_void_p, c_double_p, c_double_p, C.c_double, C.c_double, C.c_double, C.c_int]),
         "aarect": (C.c_int, [C.c_void_p, C.c_int] + [C.c_double] * 5 + [C.c_int]),
@@ -200,6 +201,13 @@ class SceneBuilder:
 
     def Isotropic(self, albedo: Handle) -> Handle:
         return self._chk("material", self._call("material_isotropic", albedo.id))
+
+    def PBR(self, base_color: Handle, metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen,
+            sheen_tint, clearcoat, clearcoat_gloss) -> Handle:
+        """PBR::new (src/mat.rs:101), the principled material; same argument order."""
+        p = (C.c_double * 10)(*[float(x) for x in (metallic, subsurface, specular, roughness, specular_tint, anisotropic,
+                                                   sheen, sheen_tint, clearcoat, clearcoat_gloss)])
+        return self._chk("material", self._call("material_pbr", base_color.id, p))
 
     # hittables
     def Sphere(self, center, radius, material: Handle) -> Handle:

@@ -25,7 +25,7 @@ static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_er
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> static void free_device_scene(DeviceScene<T>& d) {
     free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
-    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image);
+    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
     d.valid = false;
 }
 
@@ -121,6 +121,13 @@ int rt_material_dielectric(rt_scene* sc, double ir) { DMaterial<double> m{}; m.k
 int rt_material_diffuse_light(rt_scene* sc, int tex) {
     if (!tex_ok(sc, tex)) return scene_err(sc, "DiffuseLight: bad texture handle");
     DMaterial<double> m{}; m.kind = M_DIFFUSE_LIGHT; m.tex = (uint32_t)tex; return add_mat(sc, m);
+}
+int rt_material_pbr(rt_scene* sc, int tex, const double p[10]) {
+    if (!tex_ok(sc, tex)) return scene_err(sc, "PBR: bad texture handle");
+    if (!p) return scene_err(sc, "PBR: null parameters");
+    DPbr<double> d{p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8], p[9]};
+    sc->s.pbr.push_back(d);
+    DMaterial<double> m{}; m.kind = M_PBR; m.tex = (uint32_t)tex; m.albedo[0] = (double)(sc->s.pbr.size() - 1); return add_mat(sc, m);
 }
 int rt_material_isotropic(rt_scene* sc, int tex) {
     if (!tex_ok(sc, tex)) return scene_err(sc, "Isotropic: bad texture handle");
@@ -268,6 +275,10 @@ template <typename T> void cv(const DOp<double>& a, DOp<T>& b) { b.kind = a.kind
 template <typename T> void cv(const DBvhNode<double>& a, DBvhNode<T>& b) { for (int k = 0; k < 3; k++) { b.mn[k] = (T)a.mn[k]; b.mx[k] = (T)a.mx[k]; } b.a = a.a; b.b = a.b; }
 template <typename T> void cv(const DMaterial<double>& a, DMaterial<T>& b) { b.kind = a.kind; b.tex = a.tex; for (int k = 0; k < 3; k++) b.albedo[k] = (T)a.albedo[k]; b.param = (T)a.param; }
 template <typename T> void cv(const DTexture<double>& a, DTexture<T>& b) { b.kind = a.kind; b.a = a.a; b.b = a.b; b.c = a.c; for (int k = 0; k < 3; k++) b.color[k] = (T)a.color[k]; b.scale = (T)a.scale; }
+template <typename T> void cv(const DPbr<double>& a, DPbr<T>& b) {
+    b.metallic = (T)a.metallic; b.subsurface = (T)a.subsurface; b.specular = (T)a.specular; b.roughness = (T)a.roughness; b.specular_tint = (T)a.specular_tint;
+    b.anisotropic = (T)a.anisotropic; b.sheen = (T)a.sheen; b.sheen_tint = (T)a.sheen_tint; b.clearcoat = (T)a.clearcoat; b.clearcoat_gloss = (T)a.clearcoat_gloss;
+}
 template <typename T> void cv(const DMedium<double>& a, DMedium<T>& b) { b.neg_inv_density = (T)a.neg_inv_density; b.mat = a.mat; b.pad = 0; }
 
 template <typename DT, typename ST> int upload_vec(const std::vector<ST>& src, void*& dst) {
@@ -310,6 +321,7 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
         std::memcpy(pl[i].perm_z, s.perlins[i].perm[2], 256);
     }
     if (upload_raw(pl, d.perlins)) return -1;
+    if (upload_vec<DPbr<T>>(s.pbr, d.pbr)) return -1;
     if (upload_raw(s.image_bytes, d.image)) return -1;
     d.valid = true;
     return 0;
@@ -333,7 +345,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
-    P.perlins = (const DPerlin<T>*)d.perlins; P.image_bytes = (const uint8_t*)d.image;
+    P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     P.stack_depth = f.bvh_depth;
     rt_camera_args ca; std::memcpy(&ca, camp, sizeof(ca));
     DCamera<double> cam; camera_new(ca, cam);

@@ -23,7 +23,7 @@ namespace rt {
 
 enum GeomKind : uint32_t { G_RECT = 0, G_SPHERE = 1, G_MSPHERE = 2, G_TRI = 3, G_BVH = 4 };
 enum OpKind : uint32_t { OP_TRANSLATE = 0, OP_ROTATE = 1, OP_FLIP = 2 };
-enum MatKind : uint32_t { M_LAMBERTIAN = 0, M_METAL = 1, M_DIELECTRIC = 2, M_DIFFUSE_LIGHT = 3, M_ISOTROPIC = 4 };
+enum MatKind : uint32_t { M_LAMBERTIAN = 0, M_METAL = 1, M_DIELECTRIC = 2, M_DIFFUSE_LIGHT = 3, M_ISOTROPIC = 4, M_PBR = 5 };
 enum TexKind : uint32_t { T_CONSTANT = 0, T_CHECK = 1, T_NOISE = 2, T_IMAGE = 3 };
 enum LightKind : uint32_t { L_RECT = 0, L_SPHERE = 1, L_OTHER = 2 };
 
@@ -35,7 +35,8 @@ enum Feat : uint32_t {
     F_MEDIUM = 1u << 3,     // ConstantMedium
     F_TEXTURES = 1u << 4,   // Check / Noise / Image textures
     F_DIELECTRIC = 1u << 5, // Dielectric material
-    F_ALL = 0x3F
+    F_PBR = 1u << 6,        // principled material (PBR) + PDF::BRDF
+    F_ALL = 0x7F
 };
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // node.a: bit 31 leaf, bits 28..30 GeomKind, bits 0..27 first index
@@ -49,7 +50,8 @@ template <typename T> struct DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };
 template <typename T> struct DOp { uint32_t kind, axis; T x, y, z; };                         // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
 struct DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
 template <typename T> struct DBvhNode { T mn[3], mx[3]; uint32_t a, b; };                     // f64: 56 B -> padded to 64
-template <typename T> struct DMaterial { uint32_t kind, tex; T albedo[3]; T param; };         // metal: albedo, fuzz; dielectric: param = ir
+template <typename T> struct DMaterial { uint32_t kind, tex; T albedo[3]; T param; };         // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
+template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
 template <typename T> struct DTexture { uint32_t kind, a, b, c; T color[3]; T scale; };       // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height
 template <typename T> struct DMedium { T neg_inv_density; uint32_t mat, pad; };               // -(1.0/density), src/medium.rs:42
 struct DLight { uint32_t kind, index; };
@@ -73,6 +75,7 @@ template <typename T> struct KParams {
     const DMedium<T>* media;
     const DLight* lights; uint32_t n_lights;
     const DPerlin<T>* perlins;
+    const DPbr<T>* pbr;
     const uint8_t* image_bytes;
     uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS
     // frame

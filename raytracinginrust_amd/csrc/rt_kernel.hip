@@ -60,6 +60,7 @@ template <typename T> DEV DOp<T> ld_op(const DOp<T>* p) { DOp<T> r; r.kind = cl(
 DEV DObject ld_obj(const DObject* p) { DObject r; r.geom_kind = cl(&p->geom_kind); r.geom_first = cl(&p->geom_first); r.geom_count = cl(&p->geom_count); r.first_op = cl(&p->first_op); r.n_ops = cl(&p->n_ops); r.medium = cl(&p->medium); r.pad0 = r.pad1 = 0; return r; }
 template <typename T> DEV DBvhNode<T> ld_node(const DBvhNode<T>* p) { DBvhNode<T> r; for (int k = 0; k < 3; k++) { r.mn[k] = cl(&p->mn[k]); r.mx[k] = cl(&p->mx[k]); } r.a = cl(&p->a); r.b = cl(&p->b); return r; }
 template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r; r.kind = cl(&p->kind); r.tex = cl(&p->tex); for (int k = 0; k < 3; k++) r.albedo[k] = cl(&p->albedo[k]); r.param = cl(&p->param); return r; }
+template <typename T> DEV DPbr<T> ld_pbr(const DPbr<T>* p) { DPbr<T> r; r.metallic = cl(&p->metallic); r.subsurface = cl(&p->subsurface); r.specular = cl(&p->specular); r.roughness = cl(&p->roughness); r.specular_tint = cl(&p->specular_tint); r.anisotropic = cl(&p->anisotropic); r.sheen = cl(&p->sheen); r.sheen_tint = cl(&p->sheen_tint); r.clearcoat = cl(&p->clearcoat); r.clearcoat_gloss = cl(&p->clearcoat_gloss); return r; }
 template <typename T> DEV DTexture<T> ld_tex(const DTexture<T>* p) { DTexture<T> r; r.kind = cl(&p->kind); r.a = cl(&p->a); r.b = cl(&p->b); r.c = cl(&p->c); for (int k = 0; k < 3; k++) r.color[k] = cl(&p->color[k]); r.scale = cl(&p->scale); return r; }
 DEV DLight ld_light(const DLight* p) { DLight r; r.kind = cl(&p->kind); r.index = cl(&p->index); return r; }
 
@@ -113,6 +114,10 @@ DEV void sincos_0_2pi(float phi, float& sn, float& cs) { ::sincosf(phi, &sn, &cs
 DEV double m_log(double x) { return ::log(x); }   DEV float m_log(float x) { return ::logf(x); }
 DEV double m_acos(double x) { return ::acos(x); } DEV float m_acos(float x) { return ::acosf(x); }
 DEV double m_atan2(double y, double x) { return ::atan2(y, x); } DEV float m_atan2(float y, float x) { return ::atan2f(y, x); }
+DEV double m_pow(double x, double y) { return ::pow(x, y); } DEV float m_pow(float x, float y) { return ::powf(x, y); }
+DEV double m_log2(double x) { return ::log2(x); } DEV float m_log2(float x) { return ::log2f(x); }
+DEV double m_tan(double x) { return ::tan(x); } DEV float m_tan(float x) { return ::tanf(x); }
+DEV double m_atan(double x) { return ::atan(x); } DEV float m_atan(float x) { return ::atanf(x); }
 DEV double m_floor(double x) { return ::floor(x); } DEV float m_floor(float x) { return ::floorf(x); }
 DEV double m_abs(double x) { return ::fabs(x); }  DEV float m_abs(float x) { return ::fabsf(x); }
 DEV double m_max(double a, double b) { return ::fmax(a, b); } DEV float m_max(float a, float b) { return ::fmaxf(a, b); }   // f64::max: NaN-ignoring
@@ -583,6 +588,115 @@ template <typename T, uint32_t FEATS> DEV V3<T> light_random(const KParams<T>& P
     return mk<T>(T(1.0), T(0), T(0));                                                 // Hittable::random default, hit.rs:30
 }
 
+// ------------------------------------------------------------------ principled ("Disney") material: mat.rs:10-52,133-195; pdf.rs:20-60,97-130,151-160
+template <typename T> DEV T mixf(T a, T b, T t) { return a * (T(1.0) - t) + b * t; }                                                       // mat.rs:50-52
+template <typename T> DEV V3<T> mixv(V3<T> a, V3<T> b, T t) { return mk<T>(a.x * (T(1.0) - t) + b.x * t, a.y * (T(1.0) - t) + b.y * t, a.z * (T(1.0) - t) + b.z * t); }   // vec.rs:60-68
+template <typename T> DEV T schlick_fresnel(T u) { T m = clamp_(T(1.0) - u, T(0), T(1.0)); T m2 = m * m; return m2 * m2 * m; }            // mat.rs:10-14
+template <typename T> DEV T GTR_1(T n_dot_h, T a) {                                                                                        // mat.rs:16-24
+    if (a >= T(1.0)) return T(1.0) / PI_T;
+    T a2 = a * a;
+    T t = T(1.0) + (a2 - T(1.0)) * n_dot_h * n_dot_h;
+    return (a2 - T(1.0)) / (PI_T * m_log2(a2) * t);
+}
+template <typename T> DEV T GTR_2_aniso(T n_dot_h, T h_dot_x, T h_dot_y, T ax, T ay) {                                                     // mat.rs:32-34
+    T p = h_dot_x / ax, q = h_dot_y / ay;
+    T s = p * p + q * q + n_dot_h * n_dot_h;
+    return T(1.0) / (PI_T * ax * ay * (s * s));
+}
+template <typename T> DEV T smithG_GGX(T n_dot_v, T alphaG) { T a = alphaG * alphaG, b = n_dot_v * n_dot_v; return T(1.0) / (n_dot_v + rsqrt_(a + b - a * b)); }   // mat.rs:36-40
+template <typename T> DEV T smithG_GGX_aniso(T n_dot_v, T v_dot_x, T v_dot_y, T ax, T ay) {                                                // mat.rs:42-44
+    T p = v_dot_x * ax, q = v_dot_y * ay;
+    return T(1.0) / (n_dot_v + rsqrt_(p * p + q * q + n_dot_v * n_dot_v));
+}
+template <typename T> DEV V3<T> reflect_(V3<T> v, V3<T> n) { return v + ((-dot(v, n)) * T(2.0) * n); }                                      // vec.rs:112-114
+
+// Material::brdf for PBR, mat.rs:133-195
+template <typename T> DEV V3<T> pbr_brdf(const DPbr<T>& m, V3<T> base, V3<T> r_in_dir, V3<T> r_out_dir, V3<T> normal) {
+    V3<T> l = normalized(r_in_dir) * T(-1.0);
+    V3<T> v = normalized(r_out_dir);
+    Onb<T> onb = onb_from_w(normal);
+    V3<T> n = onb.w, x = onb.u, y = onb.v;
+    T n_dot_v = dot(n, v);
+    T n_dot_l = dot(n, l);
+    if (n_dot_l < T(0) || n_dot_v < T(0)) return mk<T>(T(0), T(0), T(0));
+    V3<T> h = normalized(l + v);
+    T n_dot_h = dot(n, h);
+    T l_dot_h = dot(l, h);
+    V3<T> cd_lin = mk<T>(m_pow(base.x, T(2.2)), m_pow(base.y, T(2.2)), m_pow(base.z, T(2.2)));                     // mon_to_lin, mat.rs:46-48
+    T cd_lum = T(0.3) * cd_lin.x + T(0.6) * cd_lin.y + T(0.1) * cd_lin.z;
+    V3<T> one = mk<T>(T(1.0), T(1.0), T(1.0));
+    V3<T> c_tint = (cd_lum > T(0)) ? cd_lin / cd_lum : one;
+    V3<T> c_spec0 = mixv(mixv(one, c_tint, m.specular_tint) * T(0.08) * m.specular, cd_lin, m.metallic);
+    V3<T> c_sheen = mixv(one, c_tint, m.sheen_tint);
+    T fresnel_l = schlick_fresnel(n_dot_l);
+    T fresnel_v = schlick_fresnel(n_dot_v);
+    T fresnel_diffuse_90 = T(0.5) + T(2.0) * l_dot_h * l_dot_h * m.roughness;
+    T fresnel_diffuse = mixf(T(1.0), fresnel_diffuse_90, fresnel_l) * mixf(T(1.0), fresnel_diffuse_90, fresnel_v);
+    T fss90 = l_dot_h * l_dot_h * m.roughness;
+    T fss = mixf(T(1.0), fss90, fresnel_l) * mixf(T(1.0), fss90, fresnel_v);
+    T subface_scatter = T(1.25) * (fss * (T(1.0) / (n_dot_l + n_dot_v) - T(0.5)) + T(0.5));
+    T aspect = rsqrt_(T(1.0) - m.anisotropic * T(0.9));
+    T ax = m_max(m.roughness * m.roughness / aspect, T(0.001));
+    T ay = m_max(m.roughness * m.roughness * aspect, T(0.001));
+    T d_specular = GTR_2_aniso(n_dot_h, dot(h, x), dot(h, y), ax, ay);
+    T fresnel_h = schlick_fresnel(l_dot_h);
+    V3<T> f_specular = mixv(c_spec0, one, fresnel_h);
+    T g_specular = smithG_GGX_aniso(n_dot_l, dot(l, x), dot(l, y), ax, ay) * smithG_GGX_aniso(n_dot_v, dot(v, x), dot(v, y), ax, ay);
+    V3<T> fresnel_sheen = (fresnel_h * m.sheen) * c_sheen;
+    T d_reflect = GTR_1(n_dot_h, mixf(T(0.1), T(0.001), m.clearcoat_gloss));
+    T f_reflect = mixf(T(0.04), T(1.0), fresnel_h);
+    T g_reflect = smithG_GGX(n_dot_l, T(0.25)) * smithG_GGX(n_dot_v, T(0.25));
+    return (((T(1.0) / PI_T) * mixf(fresnel_diffuse, subface_scatter, m.subsurface)) * cd_lin + fresnel_sheen) * (T(1.0) - m.metallic)
+           + (g_specular * f_specular) * d_specular + (((mk<T>(T(0.25), T(0.25), T(0.25)) * m.clearcoat) * g_reflect) * f_reflect) * d_reflect;
+}
+// PDF::BRDF value, pdf.rs:97-130
+template <typename T> DEV T brdf_pdf_value(const DPbr<T>& m, const Onb<T>& uvw, V3<T> r_in, V3<T> r_out) {
+    T cosine = dot(normalized(r_out), uvw.w);
+    if (cosine <= T(0)) return T(0);
+    T diffuse_pdf = cosine / PI_T;
+    V3<T> l = normalized(r_in) * T(-1.0);
+    V3<T> v = normalized(r_out);
+    T n_dot_l = dot(uvw.w, l);
+    V3<T> h = normalized(l + v);
+    T n_dot_h = dot(uvw.w, h);
+    if (n_dot_h <= T(0)) return T(0);
+    T aspect = rsqrt_(T(1.0) - m.anisotropic * T(0.9));
+    T ax = m_max(m.roughness * m.roughness / aspect, T(0.001));
+    T ay = m_max(m.roughness * m.roughness * aspect, T(0.001));
+    T specular_pdf = GTR_2_aniso(n_dot_h, dot(h, uvw.u), dot(h, uvw.v), ax, ay) * m_abs(n_dot_h) * T(0.25) / n_dot_l;
+    T clearcoat_pdf = GTR_1(n_dot_h, mixf(T(0.1), T(0.001), m.clearcoat_gloss)) * m_abs(n_dot_h) * T(0.25) / n_dot_l;
+    return (diffuse_pdf + specular_pdf + clearcoat_pdf) / T(3.0);
+}
+// PDF::BRDF generate, pdf.rs:151-160 with GTR_1_direction :24-36 and GTR_2_aniso_direction :38-60
+template <typename T> DEV V3<T> brdf_pdf_generate(const DPbr<T>& m, const Onb<T>& uvw, V3<T> r_in, Rng& rng) {
+    T pick = rng_range(rng, T(0), T(1.0));
+    if (pick < T(0.333)) return onb_local(uvw, random_cosine_direction<T>(rng));
+    T r1 = rng_range(rng, T(0), T(1.0));
+    T r2 = rng_range(rng, T(0), T(1.0));
+    T sin_theta, cos_theta, phi;
+    if (pick < T(0.666)) {
+        T a = mixf(T(0.1), T(0.001), m.clearcoat_gloss);
+        T a2 = a * a;
+        cos_theta = rsqrt_(m_max(T(0.001), (T(1.0) - m_pow(a2, T(1.0) - r1)) / (T(1.0) - a2)));
+        sin_theta = rsqrt_(m_max(T(0.001), T(1.0) - cos_theta * cos_theta));
+        phi = PI_T * T(2.0) * r2;
+    } else {
+        T aspect = rsqrt_(T(1.0) - m.anisotropic * T(0.9));
+        T ax = m_max(m.roughness * m.roughness / aspect, T(0.001));
+        T ay = m_max(m.roughness * m.roughness * aspect, T(0.001));
+        phi = m_atan(ay / ax * m_tan(T(2.0) * PI_T * r2 + T(0.5) * PI_T));
+        if (r2 > T(0.5)) phi += PI_T;
+        T sin_phi = m_sin(phi), cos_phi = m_cos(phi);
+        T ax_2 = ax * ax, ay_2 = ay * ay;
+        T a2 = T(1.0) / (cos_phi * cos_phi / ax_2 + sin_phi * sin_phi / ay_2);
+        T tan_theta_2 = a2 * r1 / (T(1.0) - r1);
+        cos_theta = T(1.0) / rsqrt_(T(1.0) + tan_theta_2);
+        sin_theta = rsqrt_(m_max(T(0.001), T(1.0) - cos_theta * cos_theta));
+    }
+    V3<T> wh = mk<T>(sin_theta * m_cos(phi), sin_theta * m_sin(phi), cos_theta);      // spherical_direction, pdf.rs:20-22
+    return onb_local(uvw, reflect_(r_in, wh));
+}
+
 // ------------------------------------------------------------------ wave helpers
 DEV uint32_t lane_rank(unsigned long long mask) {   // number of set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -846,6 +960,28 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
                             direction = r_out_perp + r_out_para;
                         }
                         ray.o = rec.p; ray.d = direction;                                   // attenuation (1,1,1): beta unchanged
+                    } else if ((FEATS & F_PBR) && mt.kind == M_PBR) {                       // mat.rs:118-131 + main.rs:99-105 (Microfacet arm)
+                        const DPbr<T> pm = ld_pbr(P.pbr + (uint32_t)mt.albedo[0]);
+                        Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::brdf_pdf, pdf.rs:70-79
+                        V3<T> dir; T pdf_value;
+                        if (P.n_lights == 0u) {                                             // stated deviation D2
+                            dir = brdf_pdf_generate(pm, uvw, ray.d, rng);
+                            pdf_value = brdf_pdf_value(pm, uvw, ray.d, dir);
+                        } else {
+                            if (rng_bool(rng)) {
+                                uint32_t li = rng_index(rng, P.n_lights);
+                                dir = light_random<T, FEATS>(P, ld_light(P.lights + li), rec.p, rng);
+                            } else {
+                                dir = brdf_pdf_generate(pm, uvw, ray.d, rng);
+                            }
+                            T lsum = T(0);
+                            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
+                            pdf_value = T(0.5) * (lsum / T(P.n_lights)) + T(0.5) * brdf_pdf_value(pm, uvw, ray.d, dir);
+                        }
+                        V3<T> base = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+                        V3<T> f = pbr_brdf(pm, base, ray.d, dir, rec.n);
+                        beta = (beta * f) / pdf_value;                                      // main.rs:104
+                        ray.o = rec.p; ray.d = dir;
                     } else if (mt.kind == M_DIFFUSE_LIGHT) {                                // mat.rs:395-401; no scatter -> main.rs:108-110
                         if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
                         done = true;
@@ -901,16 +1037,19 @@ static int occupancy_one(size_t shmem) {
     return nb;
 }
 
-// Two instantiations per arithmetic type: the lean one (rects + instances + Lambertian/Metal/DiffuseLight —
-// everything the Cornell box needs) and the full one.
+// Three instantiations per arithmetic type: the lean one (rects + instances + Lambertian/Metal/DiffuseLight — everything
+// the Cornell box needs), the full one without the principled material, and the full one with it.
 static const uint32_t FEATS_LEAN = 0u;
+static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
 
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
     if ((scene_feats & ~FEATS_LEAN) == 0u) return launch_one<T, FEATS_LEAN>(P, n_blocks, shmem, stream);
+    if ((scene_feats & ~FEATS_NO_PBR) == 0u) return launch_one<T, FEATS_NO_PBR>(P, n_blocks, shmem, stream);
     return launch_one<T, F_ALL>(P, n_blocks, shmem, stream);
 }
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, size_t shmem) {
     if ((scene_feats & ~FEATS_LEAN) == 0u) return occupancy_one<T, FEATS_LEAN>(shmem);
+    if ((scene_feats & ~FEATS_NO_PBR) == 0u) return occupancy_one<T, FEATS_NO_PBR>(shmem);
     return occupancy_one<T, F_ALL>(shmem);
 }
 

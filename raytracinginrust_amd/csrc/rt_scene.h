@@ -40,7 +40,7 @@ template <typename T> struct DeviceScene {   // device copies of HostFlat for on
     bool valid = false;
     void* objects = nullptr; void* ops = nullptr; void* rects = nullptr; void* spheres = nullptr; void* mspheres = nullptr;
     void* tris = nullptr; void* bvh = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
-    void* lights = nullptr; void* perlins = nullptr; void* image = nullptr;
+    void* lights = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr;
 };
 
 struct Scene {
@@ -48,6 +48,7 @@ struct Scene {
     std::vector<DMaterial<double>> materials;
     std::vector<DTexture<double>> textures;
     std::vector<HPerlin> perlins;
+    std::vector<DPbr<double>> pbr;
     std::vector<uint8_t> image_bytes;
     int world = -1;
     std::vector<int> lights;

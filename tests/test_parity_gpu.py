@@ -187,6 +187,35 @@ def test_sphere_light_and_wrapped_instances(pbe, obe, orc_mod):
     assert ref.mean() > 0.0
 
 
+@pytest.mark.parametrize("with_lights", [True, False])
+def test_principled_material_parity(pbe, obe, orc_mod, with_lights):
+    """PBR + PDF::BRDF + the Microfacet arm (mat.rs:84-197, pdf.rs:97-160, main.rs:99-105), incl. its NaN samples."""
+    def build(be):
+        b = SceneBuilder(be)
+        a = b.PBR(b.ConstantTexture((0.8, 0.3, 0.2)), 0.2, 0.1, 0.5, 0.4, 0.3, 0.2, 0.3, 0.5, 0.6, 0.8)
+        c = b.PBR(b.ConstantTexture((0.9, 0.9, 0.9)), 1.0, 0.0, 0.5, 0.15, 0.0, 0.6, 0.0, 0.0, 0.0, 0.0)
+        d = b.PBR(b.CheckTexture(b.ConstantTexture((0.2, 0.8, 0.3)), b.ConstantTexture((0.9, 0.9, 0.2))), 0.0, 0.8, 0.2, 0.9, 0.5, 0.0, 1.0, 0.5, 1.0, 0.2)
+        light = b.DiffuseLight(b.ConstantTexture((10.0, 10.0, 10.0)))
+        rect_light = b.FlipNormal(b.AARect(Plane.XZ, -20.0, 20.0, -20.0, 20.0, 60.0, light))
+        world = b.HittableList()
+        world.push(b.Sphere((-22.0, 10.0, 0.0), 10.0, a))
+        world.push(b.Sphere((0.0, 10.0, 5.0), 10.0, c))
+        world.push(b.Translate(b.Rotate(Axis.Y, b.Cube((0.0, 0.0, 0.0), (14.0, 18.0, 14.0), d), 25.0), (14.0, 0.0, -8.0)))
+        world.push(b.AARect(Plane.XZ, -100.0, 100.0, -100.0, 100.0, 0.0, b.Lambertian(b.ConstantTexture((0.7, 0.7, 0.7)))))
+        world.push(rect_light)
+        b.set_scene(world, [rect_light] if with_lights else [])
+        cam = Camera((0.0, 35.0, -90.0), (0.0, 10.0, 0.0), (0.0, 1.0, 0.0), 35.0, 1.0, 0.5, 95.0, 0.0, 1.0)
+        return b, cam, (0.1, 0.1, 0.15)
+    ob, ocam, obg = build(obe)
+    pb, pcam, pbg = build(pbe)
+    ref, rs, cnt = orc_mod.render(ob, ocam, obg, 40, 40, 16, 12, want_samples=True, want_counters=True)
+    got, gs = R.render(pb, pcam, pbg, 40, 40, 16, 12, want_samples=True)
+    n_bad, _, _ = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED
+    assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+    assert np.isfinite(rs).all(axis=-1).mean() > 0.5
+
+
 def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
     b, cam, bg = _cornell(pbe)
     a = R.render(b, cam, bg, 64, 64, 32, 50)
