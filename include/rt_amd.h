@@ -39,8 +39,10 @@ typedef struct rt_camera {
 enum {
     RT_F64 = 0,            /* reference precision (default): every operation in f64                         */
     RT_F32 = 1,            /* throughput variant: f32 arithmetic (statistical parity only)                   */
-    RT_STOP_ON_ZERO = 2    /* opt-in: end a path whose throughput is exactly (0,0,0); differs from the
+    RT_STOP_ON_ZERO = 2,   /* opt-in: end a path whose throughput is exactly (0,0,0); differs from the
                               reference only where a later bounce would have produced NaN (0*NaN)            */
+    RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
+                              old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };
 
 const char* rt_last_error(void);

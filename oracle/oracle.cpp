@@ -637,7 +637,16 @@ struct DiffuseLight : Material {                                       // mat.rs
 };
 struct Isotropic : Material {                                          // mat.rs:404-422: only the old `scatter` is implemented,
     const Texture* albedo;                                             // so on the scatter_mc_method path it absorbs
-    explicit Isotropic(const Texture* t) : albedo(t) {}
+    const bool* scatters;                                              // opt-in, NOT reference behaviour: run the old `scatter`
+    Isotropic(const Texture* t, const bool* opt) : albedo(t), scatters(opt) {}
+    bool scatter_mc_method(const Ray& r_in, const HitRecord& rec, Sampler& s, ScatterRecord& out) const override {
+        if (!scatters || !*scatters) return false;                     // the committed code: trait default None (mat.rs:61-63)
+        // mat.rs:418-421 under the old estimator `emitted + attenuation * ray_color(scattered)` (main.rs:84-85, commented out)
+        out.kind = ScatterRecord::Specular;
+        out.specular_ray = Ray(rec.position, random_in_unit_sphere(s), r_in.time());
+        out.attenuation = albedo->mapping(rec.u, rec.v, rec.position, s);
+        return true;
+    }
 };
 
 // ---------------------------------------------------------------- src/sphere.rs
@@ -923,7 +932,7 @@ struct Rotate : Hittable {
 // ---------------------------------------------------------------- src/medium.rs
 struct ConstantMedium : Hittable {
     const Hittable* boundary; double density; Isotropic phase_function;
-    ConstantMedium(const Hittable* b, double d, const Texture* t) : boundary(b), density(d), phase_function(t) {}
+    ConstantMedium(const Hittable* b, double d, const Texture* t, const bool* opt) : boundary(b), density(d), phase_function(t, opt) {}
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // medium.rs:27-61
         s.c.medium_tests++;
         HitRecord hit1, hit2;
@@ -1067,6 +1076,7 @@ struct Scene {
     std::vector<std::unique_ptr<Hittable>> hittables;
     const Hittable* world = nullptr;
     HittableList lights;            // always a list, as in every scene fn of main.rs
+    bool isotropic_scatters = false; // opt-in non-reference mode (see Isotropic)
     std::string error;
     int add(Hittable* h) { hittables.emplace_back(h); return (int)hittables.size() - 1; }
     int add(Material* m) { materials.emplace_back(m); return (int)materials.size() - 1; }
@@ -1122,7 +1132,8 @@ int orc_material_lambertian(void* s, int tex) { return SC->add(new Lambertian(SC
 int orc_material_metal(void* s, const double* albedo, double fuzz) { return SC->add(new Metal(V(albedo), fuzz)); }
 int orc_material_dielectric(void* s, double ir) { return SC->add(new Dielectric(ir)); }
 int orc_material_diffuse_light(void* s, int tex) { return SC->add(new DiffuseLight(SC->textures[tex].get())); }
-int orc_material_isotropic(void* s, int tex) { return SC->add(new Isotropic(SC->textures[tex].get())); }
+int orc_material_isotropic(void* s, int tex) { return SC->add(new Isotropic(SC->textures[tex].get(), &SC->isotropic_scatters)); }
+void orc_scene_set_isotropic_scatters(void* s, int on) { SC->isotropic_scatters = on != 0; }
 int orc_material_pbr(void* s, int tex, const double* params10) { return SC->add(new PBR(SC->textures[tex].get(), params10)); }
 
 #define MAT(m) (SC->materials[m].get())
@@ -1150,7 +1161,7 @@ int orc_mesh(void* s, const double* positions, uint32_t npos, const uint32_t* in
 int orc_flip_normal(void* s, int h) { return SC->add(new FlipNormal(HIT(h))); }
 int orc_translate(void* s, int h, const double* offset) { return SC->add(new Translate(HIT(h), V(offset))); }
 int orc_rotate(void* s, int axis, int h, double angle) { return SC->add(new Rotate(axis, HIT(h), angle)); }
-int orc_constant_medium(void* s, int boundary, double density, int tex) { return SC->add(new ConstantMedium(HIT(boundary), density, SC->textures[tex].get())); }
+int orc_constant_medium(void* s, int boundary, double density, int tex) { return SC->add(new ConstantMedium(HIT(boundary), density, SC->textures[tex].get(), &SC->isotropic_scatters)); }
 int orc_bvh(void* s, const int* ids, uint32_t n, double t0, double t1) {
     if (n == 0) { SC->error = "no object in the scene"; return -1; }
     std::vector<const Hittable*> v;

@@ -112,6 +112,11 @@ def render(b, cam, background, W, H, spp, max_depth, seed=0x5EED, want_samples=F
     return res[0] if len(res) == 1 else tuple(res)
 
 
+def set_isotropic_scatters(b, on: bool):
+    """Opt-in, non-reference: Isotropic runs its old `scatter` (mat.rs:417-421) — mirrors the product's RT_ISOTROPIC_SCATTER."""
+    load().lib.orc_scene_set_isotropic_scatters(C.c_void_p(b.h), 1 if on else 0)
+
+
 def algorithmic_bytes_per_sample(counters: dict, spp: int) -> float:
     """sum over path events x record size, plus the framebuffer write amortised over spp."""
     n = counters["samples"]

@@ -268,7 +268,7 @@ struct Flattener {
         f = HostFlat{};
         f.materials = s.materials;
         f.textures = s.textures;
-        for (const auto& m : f.materials) { if (m.kind == M_DIELECTRIC) f.feats |= F_DIELECTRIC; if (m.kind == M_PBR) f.feats |= F_PBR; }
+        for (const auto& m : f.materials) { if (m.kind == M_DIELECTRIC) f.feats |= F_DIELECTRIC; if (m.kind == M_PBR) f.feats |= F_PBR; if (m.kind == M_ISOTROPIC) f.feats |= F_MEDIUM; }
         for (const auto& t : f.textures) if (t.kind != T_CONSTANT) f.feats |= F_TEXTURES;
         if (s.world < 0) return fail("world not set");
         Chain c;

@@ -985,6 +985,10 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(c
                     } else if (mt.kind == M_DIFFUSE_LIGHT) {                                // mat.rs:395-401; no scatter -> main.rs:108-110
                         if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
                         done = true;
+                    } else if ((FEATS & F_MEDIUM) && (P.flags & 4u) && mt.kind == M_ISOTROPIC) {   // RT_ISOTROPIC_SCATTER (opt-in, non-reference):
+                        V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);     // the old Isotropic::scatter, mat.rs:418-421
+                        V3<T> sd = random_in_unit_sphere<T>(rng);
+                        beta = attenuation * beta; ray.o = rec.p; ray.d = sd;
                     } else {                                                                // Isotropic: no scatter_mc_method (mat.rs:417-422) -> absorbs
                         done = true;
                     }

@@ -3,7 +3,7 @@
 // reference is Rust, this environment has no Rust toolchain, so the host is C++ over include/raytracinginrust.hpp
 // (same constructor names and argument order).  Usage mirrors `cargo run --release > image.ppm` (README.md:4):
 //
-//     rtrender [--scene cornell|random|final|teapot] [--width W] [--height H] [--spp N] [--depth D]
+//     rtrender [--scene cornell|random|final|teapot|two_sphere|two_perlin|earth|light_room|smoke|progress] [--width W] [--height H] [--spp N] [--depth D]
 //              [--seed S] [--obj teapot.obj] [--earth earth.ppm] [--f32] > image.ppm
 //
 // The reference hard-codes its settings as consts (main.rs:579-583, :623); they are flags here.
@@ -39,7 +39,65 @@ Mesh Mesh::load_obj(Scene& s, const std::string& path, Vec3 offset, double scale
     return Mesh::new_(s, pos, idx, m);
 }
 
-static const uint32_t STREAM_RANDOM_SCENE = 0, STREAM_FINAL_SCENE = 1;
+static const uint32_t STREAM_RANDOM_SCENE = 0, STREAM_FINAL_SCENE = 1, STREAM_TWO_PERLIN = 2;
+
+// src/main.rs:212-227
+static void two_spehre(Scene& s) {
+    HittableList world(s);
+    Material top_mat = Lambertian::new_(s, CheckTexture::new_(s, ConstantTexture::new_(s, Color(1.0, 1.0, 1.0)), ConstantTexture::new_(s, Color(0.3, 0.3, 1.0))));
+    Material bottom_mat = Lambertian::new_(s, CheckTexture::new_(s, ConstantTexture::new_(s, Color(1.0, 1.0, 1.0)), ConstantTexture::new_(s, Color(0.3, 0.3, 1.0))));
+    world.push(Sphere::new_(s, Point3(0.0, 10.0, 0.0), 10.0, top_mat));
+    world.push(Sphere::new_(s, Point3(0.0, -10.0, 0.0), 10.0, bottom_mat));
+    s.set(world, {});
+}
+// src/main.rs:229-245
+static void two_perlin_sphere(Scene& s, uint64_t seed) {
+    Rng rng(seed, STREAM_TWO_PERLIN);
+    HittableList world(s);
+    Material top_mat = Lambertian::new_(s, NoiseTexture::new_(s, 2.0, rng));
+    Material bottom_mat = Lambertian::new_(s, NoiseTexture::new_(s, 2.0, rng));
+    world.push(Sphere::new_(s, Point3(1000.0, 2.0, 1000.0), 2.0, top_mat));
+    world.push(Sphere::new_(s, Point3(1000.0, -1000.0, 1000.0), 1000.0, bottom_mat));
+    s.set(world, {});
+}
+// src/main.rs:247-255
+static void earth(Scene& s, const std::vector<uint8_t>& data, uint32_t w, uint32_t h) {
+    s.set(Sphere::new_(s, Vec3(0.0, 0.0, 0.0), 2.0, Lambertian::new_(s, ImageTexture::new_(s, data, w, h))), {});
+}
+// src/main.rs:257-276
+static void light_room(Scene& s) {
+    HittableList world(s);
+    Material bottom_mat = Lambertian::new_(s, ConstantTexture::new_(s, Color(0.7, 0.7, 0.7)));
+    Material top_mat = Lambertian::new_(s, ConstantTexture::new_(s, Color(0.0, 0.1843, 0.6549)));
+    Material emitted = DiffuseLight::new_(s, ConstantTexture::new_(s, Color(4.0, 4.0, 4.0)));
+    world.push(Sphere::new_(s, Point3(0.0, -1000.0, 0.0), 1000.0, bottom_mat));
+    world.push(Sphere::new_(s, Point3(0.0, 2.0, 0.0), 2.0, top_mat));
+    Hittable plane = AARect::new_(s, Plane::XY, 3.0, 5.0, 1.0, 3.0, -2.0, emitted);
+    world.push(plane);
+    s.set(world, {plane});
+}
+// src/main.rs:313-346
+static void cornell_box_with_smoke(Scene& s) {
+    Material red = Lambertian::new_(s, ConstantTexture::new_(s, Color(0.65, 0.05, 0.05)));
+    Material white = Lambertian::new_(s, ConstantTexture::new_(s, Color(0.73, 0.73, 0.73)));
+    Material green = Lambertian::new_(s, ConstantTexture::new_(s, Color(0.12, 0.45, 0.15)));
+    Material light = DiffuseLight::new_(s, ConstantTexture::new_(s, Color(15.0, 15.0, 15.0)));
+    Hittable rect_light = FlipNormal::new_(s, AARect::new_(s, Plane::XZ, 213.0, 343.0, 227.0, 332.0, 554.0, light));
+    HittableList world(s);
+    world.push(AARect::new_(s, Plane::YZ, 0.0, 555.0, 0.0, 555.0, 555.0, green));
+    world.push(AARect::new_(s, Plane::YZ, 0.0, 555.0, 0.0, 555.0, 0.0, red));
+    world.push(rect_light);
+    world.push(AARect::new_(s, Plane::XZ, 0.0, 555.0, 0.0, 555.0, 0.0, white));
+    world.push(AARect::new_(s, Plane::XZ, 0.0, 555.0, 0.0, 555.0, 555.0, white));
+    world.push(AARect::new_(s, Plane::XY, 0.0, 555.0, 0.0, 555.0, 555.0, white));
+    Hittable box1 = Translate::new_(s, Rotate::new_(s, Axis::Y, Cube::new_(s, Point3(0.0, 0.0, 0.0), Point3(165.0, 165.0, 165.0), white), -18.0), Vec3(130.0, 0.0, 65.0));
+    Hittable box2 = Translate::new_(s, Rotate::new_(s, Axis::Y, Cube::new_(s, Point3(0.0, 0.0, 0.0), Point3(165.0, 330.0, 165.0), white), 15.0), Vec3(265.0, 0.0, 295.0));
+    world.push(ConstantMedium::new_(s, box1, 0.01, ConstantTexture::new_(s, Color(1.0, 1.0, 1.0))));
+    world.push(ConstantMedium::new_(s, box2, 0.01, ConstantTexture::new_(s, Color(0.0, 0.0, 0.0))));
+    s.set(world, {rect_light});
+}
+// src/main.rs:515-562: the body is entirely commented out
+static void progress_showcase(Scene& s) { HittableList world(s); s.set(world, {}); }
 
 // src/main.rs:153-210
 static void random_scene(Scene& s, uint64_t seed) {
@@ -160,7 +218,7 @@ static bool read_p6(const std::string& path, std::vector<uint8_t>& data, uint32_
     return (bool)f;
 }
 
-enum class SceneKind { Random, CornellBox, CornellTest, FinalScene };     // src/main.rs:564-575 (the four BASELINE names)
+enum class SceneKind { Random, TwoSphere, TwoPerlinSphere, Earth, LightRoom, CornellBox, CornellSmoke, CornellTest, FinalScene, Progress };   // src/main.rs:564-575
 
 int main(int argc, char** argv) {
     SceneKind scene = SceneKind::CornellBox;
@@ -170,7 +228,14 @@ int main(int argc, char** argv) {
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
-        if (a == "--scene") { std::string v = next(); scene = v == "random" ? SceneKind::Random : v == "final" ? SceneKind::FinalScene : v == "teapot" ? SceneKind::CornellTest : SceneKind::CornellBox; }
+        if (a == "--scene") {
+            std::string v = next();
+            scene = v == "random" ? SceneKind::Random : v == "final" ? SceneKind::FinalScene : v == "teapot" ? SceneKind::CornellTest
+                  : v == "two_sphere" ? SceneKind::TwoSphere : v == "two_perlin" ? SceneKind::TwoPerlinSphere : v == "earth" ? SceneKind::Earth
+                  : v == "light_room" ? SceneKind::LightRoom : v == "smoke" ? SceneKind::CornellSmoke : v == "progress" ? SceneKind::Progress
+                  : SceneKind::CornellBox;
+        }
+        else if (a == "--isotropic-scatter") flags |= RT_ISOTROPIC_SCATTER;
         else if (a == "--width") image_width = (uint32_t)std::atoi(next());
         else if (a == "--height") image_height = (uint32_t)std::atoi(next());
         else if (a == "--spp") samples_per_pixel = (uint32_t)std::atoi(next());
@@ -191,6 +256,39 @@ int main(int argc, char** argv) {
             random_scene(s, seed);
             background = Color(0.7, 0.8, 1.0);
             camera = Camera::new_(Point3(13.0, 2.0, 3.0), Point3(0.0, 0.0, 0.0), vup, 20.0, aspect_ratio, 0.1, 10.0, 0.0, 1.0);
+            break;
+        case SceneKind::TwoSphere:
+            two_spehre(s);
+            background = Color(0.7, 0.8, 1.0);
+            camera = Camera::new_(Point3(13.0, 2.0, 3.0), Point3(0.0, 0.0, 0.0), vup, 20.0, aspect_ratio, 0.0, 10.0, 0.0, 1.0);
+            break;
+        case SceneKind::TwoPerlinSphere:
+            two_perlin_sphere(s, seed);
+            background = Color(0.7, 0.8, 1.0);
+            camera = Camera::new_(Point3(1013.0, 2.0, 1003.0), Point3(1000.0, 0.0, 1000.0), vup, 20.0, aspect_ratio, 0.0, 10.0, 0.0, 1.0);
+            break;
+        case SceneKind::Earth: {
+            std::vector<uint8_t> tex; uint32_t ew = 0, eh = 0;
+            if (!read_p6(earth_path, tex, ew, eh)) throw Error("image not found: " + earth_path);      // main.rs:248
+            earth(s, tex, ew, eh);
+            background = Color(0.7, 0.8, 1.0);
+            camera = Camera::new_(Point3(13.0, 2.0, 3.0), Point3(0.0, 0.0, 0.0), vup, 20.0, aspect_ratio, 0.1, 10.0, 0.0, 1.0);
+            break;
+        }
+        case SceneKind::LightRoom:
+            light_room(s);
+            background = Color(0.0, 0.0, 0.0);
+            camera = Camera::new_(Point3(26.0, 3.0, 6.0), Point3(0.0, 2.0, 0.0), vup, 20.0, aspect_ratio, 0.0, 10.0, 0.0, 1.0);
+            break;
+        case SceneKind::CornellSmoke:
+            cornell_box_with_smoke(s);
+            background = Color(0.0, 0.0, 0.0);
+            camera = Camera::new_(Point3(278.0, 278.0, -800.0), Point3(278.0, 278.0, 0.0), vup, 40.0, aspect_ratio, 0.05, 10.0, 0.0, 1.0);
+            break;
+        case SceneKind::Progress:
+            progress_showcase(s);
+            background = Color(0.0, 0.0, 0.0);
+            camera = Camera::new_(Point3(-3.3, 6.8, -9.8), Point3(0.0, 1.0, 0.0), vup, 40.0, aspect_ratio, 0.2, 12.0, 0.0, 1.0);
             break;
         case SceneKind::CornellBox:
             cornell_box(s);

@@ -3,7 +3,7 @@
 Each function returns `(builder, camera, background)`; the scene's `(world, lights)` pair is
 already attached to the builder.  Random draws (`rand::thread_rng()` in the reference) come from
 a seeded stream `Rng(backend, seed, stream)` and keep the source order of the reference's draws.
-Only the scenes BASELINE.json's configs name are here.
+All ten scene functions of the reference are here (`Scene` enum, src/main.rs:564-575).
 """
 from __future__ import annotations
 
@@ -54,6 +54,96 @@ def random_scene(backend: Backend, seed: int = DEFAULT_SEED, aspect_ratio: float
     b.set_scene(b.BVH(world, 0.0, 1.0), [])
     cam = Camera((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, aspect_ratio, 0.1, 10.0, 0.0, 1.0)
     return b, cam, (0.7, 0.8, 1.0)
+
+
+def two_spehre(backend: Backend, aspect_ratio: float = 16.0 / 9.0):
+    """src/main.rs:212-227 (name as in the reference), camera src/main.rs:640-649.  `lights` empty."""
+    b = SceneBuilder(backend)
+    world = b.HittableList()
+    top_mat = b.Lambertian(b.CheckTexture(b.ConstantTexture((1.0, 1.0, 1.0)), b.ConstantTexture((0.3, 0.3, 1.0))))
+    bottom_mat = b.Lambertian(b.CheckTexture(b.ConstantTexture((1.0, 1.0, 1.0)), b.ConstantTexture((0.3, 0.3, 1.0))))
+    world.push(b.Sphere((0.0, 10.0, 0.0), 10.0, top_mat))
+    world.push(b.Sphere((0.0, -10.0, 0.0), 10.0, bottom_mat))
+    b.set_scene(world, [])
+    cam = Camera((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, aspect_ratio, 0.0, 10.0, 0.0, 1.0)
+    return b, cam, (0.7, 0.8, 1.0)
+
+
+STREAM_TWO_PERLIN = 2
+
+
+def two_perlin_sphere(backend: Backend, seed: int = DEFAULT_SEED, aspect_ratio: float = 16.0 / 9.0):
+    """src/main.rs:229-245 (objects moved to the first quadrant because of the negative-lattice quirk, :235),
+    camera src/main.rs:654-663.  Two separate NoiseTexture::new(2.0), i.e. two Perlin tables, top first."""
+    b = SceneBuilder(backend)
+    rng = Rng(backend, seed, STREAM_TWO_PERLIN)
+    world = b.HittableList()
+    top_mat = b.Lambertian(b.NoiseTexture(2.0, rng))
+    bottom_mat = b.Lambertian(b.NoiseTexture(2.0, rng))
+    world.push(b.Sphere((1000.0, 2.0, 1000.0), 2.0, top_mat))
+    world.push(b.Sphere((1000.0, -1000.0, 1000.0), 1000.0, bottom_mat))
+    b.set_scene(world, [])
+    cam = Camera((1013.0, 2.0, 1003.0), (1000.0, 0.0, 1000.0), (0.0, 1.0, 0.0), 20.0, aspect_ratio, 0.0, 10.0, 0.0, 1.0)
+    return b, cam, (0.7, 0.8, 1.0)
+
+
+def earth(backend: Backend, earth_rgb8: bytes, earth_w: int, earth_h: int, aspect_ratio: float = 16.0 / 9.0):
+    """src/main.rs:247-255 (world is the bare sphere, not a list), camera src/main.rs:668-677."""
+    b = SceneBuilder(backend)
+    globe = b.Sphere((0.0, 0.0, 0.0), 2.0, b.Lambertian(b.ImageTexture(earth_rgb8, earth_w, earth_h)))
+    b.set_scene(globe, [])
+    cam = Camera((13.0, 2.0, 3.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0), 20.0, aspect_ratio, 0.1, 10.0, 0.0, 1.0)
+    return b, cam, (0.7, 0.8, 1.0)
+
+
+def light_room(backend: Backend, aspect_ratio: float = 16.0 / 9.0):
+    """src/main.rs:257-276, camera src/main.rs:682-691.  The XY rect light is pushed un-flipped."""
+    b = SceneBuilder(backend)
+    world = b.HittableList()
+    bottom_mat = b.Lambertian(b.ConstantTexture((0.7, 0.7, 0.7)))
+    top_mat = b.Lambertian(b.ConstantTexture((0.0, 0.1843, 0.6549)))
+    emitted = b.DiffuseLight(b.ConstantTexture((4.0, 4.0, 4.0)))
+    world.push(b.Sphere((0.0, -1000.0, 0.0), 1000.0, bottom_mat))
+    world.push(b.Sphere((0.0, 2.0, 0.0), 2.0, top_mat))
+    plane = b.AARect(Plane.XY, 3.0, 5.0, 1.0, 3.0, -2.0, emitted)
+    world.push(plane)
+    b.set_scene(world, [plane])
+    cam = Camera((26.0, 3.0, 6.0), (0.0, 2.0, 0.0), (0.0, 1.0, 0.0), 20.0, aspect_ratio, 0.0, 10.0, 0.0, 1.0)
+    return b, cam, (0.0, 0.0, 0.0)
+
+
+def cornell_box_with_smoke(backend: Backend, aspect_ratio: float = 1.0):
+    """src/main.rs:313-346, camera src/main.rs:712-719.  With the committed code the media absorb (SURVEY §0.6);
+    the RT_ISOTROPIC_SCATTER render flag gives the scattering look of img/volume.png."""
+    b = SceneBuilder(backend)
+    red = b.Lambertian(b.ConstantTexture((0.65, 0.05, 0.05)))
+    white = b.Lambertian(b.ConstantTexture((0.73, 0.73, 0.73)))
+    green = b.Lambertian(b.ConstantTexture((0.12, 0.45, 0.15)))
+    light = b.DiffuseLight(b.ConstantTexture((15.0, 15.0, 15.0)))
+    rect_light = b.FlipNormal(b.AARect(Plane.XZ, 213.0, 343.0, 227.0, 332.0, 554.0, light))
+    world = b.HittableList()
+    world.push(b.AARect(Plane.YZ, 0.0, 555.0, 0.0, 555.0, 555.0, green))
+    world.push(b.AARect(Plane.YZ, 0.0, 555.0, 0.0, 555.0, 0.0, red))
+    world.push(rect_light)
+    world.push(b.AARect(Plane.XZ, 0.0, 555.0, 0.0, 555.0, 0.0, white))
+    world.push(b.AARect(Plane.XZ, 0.0, 555.0, 0.0, 555.0, 555.0, white))
+    world.push(b.AARect(Plane.XY, 0.0, 555.0, 0.0, 555.0, 555.0, white))
+    box1 = b.Translate(b.Rotate(Axis.Y, b.Cube((0.0, 0.0, 0.0), (165.0, 165.0, 165.0), white), -18.0), (130.0, 0.0, 65.0))
+    box2 = b.Translate(b.Rotate(Axis.Y, b.Cube((0.0, 0.0, 0.0), (165.0, 330.0, 165.0), white), 15.0), (265.0, 0.0, 295.0))
+    world.push(b.ConstantMedium(box1, 0.01, b.ConstantTexture((1.0, 1.0, 1.0))))
+    world.push(b.ConstantMedium(box2, 0.01, b.ConstantTexture((0.0, 0.0, 0.0))))
+    b.set_scene(world, [rect_light])
+    cam = Camera((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), (0.0, 1.0, 0.0), 40.0, aspect_ratio, 0.05, 10.0, 0.0, 1.0)
+    return b, cam, (0.0, 0.0, 0.0)
+
+
+def progress_showcase(backend: Backend, aspect_ratio: float = 1.0):
+    """src/main.rs:515-562: every line of the body is commented out, so (world, lights) are two empty lists.
+    Camera src/main.rs:754-761.  Every ray misses: the frame is the background."""
+    b = SceneBuilder(backend)
+    b.set_scene(b.HittableList(), [])
+    cam = Camera((-3.3, 6.8, -9.8), (0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 40.0, aspect_ratio, 0.2, 12.0, 0.0, 1.0)
+    return b, cam, (0.0, 0.0, 0.0)
 
 
 def cornell_box(backend: Backend, aspect_ratio: float = 1.0):

@@ -216,6 +216,43 @@ def test_principled_material_parity(pbe, obe, orc_mod, with_lights):
     assert np.isfinite(rs).all(axis=-1).mean() > 0.5
 
 
+def _other_scene(name, be, earth):
+    if name == "two_spehre":
+        return scenes.two_spehre(be)
+    if name == "two_perlin_sphere":
+        return scenes.two_perlin_sphere(be)
+    if name == "earth":
+        return scenes.earth(be, *earth)
+    if name == "light_room":
+        return scenes.light_room(be)
+    if name == "cornell_box_with_smoke":
+        return scenes.cornell_box_with_smoke(be)
+    if name == "progress_showcase":
+        return scenes.progress_showcase(be)
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("name,scatter", [("two_spehre", False), ("two_perlin_sphere", False), ("earth", False), ("light_room", False),
+                                          ("cornell_box_with_smoke", False), ("cornell_box_with_smoke", True), ("progress_showcase", False)])
+def test_remaining_reference_scenes(pbe, obe, orc_mod, earth, name, scatter):
+    """The six scene functions no BASELINE config names (src/main.rs:212-276,313-346,515-562), and the opt-in
+    RT_ISOTROPIC_SCATTER mode on the smoke scene."""
+    ob, ocam, obg = _other_scene(name, obe, earth)
+    pb, pcam, pbg = _other_scene(name, pbe, earth)
+    W, H, spp, depth = 48, 27, 8, 20
+    if scatter:
+        orc_mod.set_isotropic_scatters(ob, True)
+    ref, rs = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
+    got, gs = R.render(pb, pcam, pbg, W, H, spp, depth, want_samples=True, flags=R.RT_ISOTROPIC_SCATTER if scatter else R.RT_F64)
+    n_bad, _, _ = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED
+    if name == "progress_showcase":
+        assert np.all(got == 0.0)                      # empty world, black background
+    if name == "cornell_box_with_smoke" and scatter:
+        absorb = R.render(pb, pcam, pbg, W, H, spp, depth)
+        assert got.mean() > absorb.mean()              # scattering media return light that absorbing media swallow
+
+
 def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
     b, cam, bg = _cornell(pbe)
     a = R.render(b, cam, bg, 64, 64, 32, 50)
@@ -279,7 +316,7 @@ def test_f32_variant_statistical_parity(pbe):
 
 
 # ------------------------------------------------------------------ the C++ host (`main.rs` restated) end to end
-@pytest.mark.parametrize("scene,depth", [("cornell", 20), ("random", 8)])
+@pytest.mark.parametrize("scene,depth", [("cornell", 20), ("random", 8), ("two_perlin", 8), ("smoke", 20)])
 def test_cxx_host_main_prints_the_same_ppm(tmp_path, pbe, scene, depth):
     """host/rtrender builds the scene with the C++ mirror of the Rust API (its own random_scene draws included) and
     prints the reference's P3 stream; it must equal the Python-built scene's image up to quantisation ties."""
@@ -291,6 +328,7 @@ def test_cxx_host_main_prints_the_same_ppm(tmp_path, pbe, scene, depth):
                          check=True, capture_output=True, text=True).stdout.split("\n")
     assert txt[:3] == ["P3", f"{W} {H}", "255"]
     got = np.array([[int(x) for x in l.split()] for l in txt[3:3 + W * H]]).reshape(H, W, 3)
-    pb, pcam, pbg = (scenes.cornell_box(pbe, aspect_ratio=W / H) if scene == "cornell" else scenes.random_scene(pbe, aspect_ratio=W / H))
+    build = {"cornell": scenes.cornell_box, "random": scenes.random_scene, "two_perlin": scenes.two_perlin_sphere, "smoke": scenes.cornell_box_with_smoke}[scene]
+    pb, pcam, pbg = build(pbe, aspect_ratio=W / H)
     ref = R.format_image(R.render(pb, pcam, pbg, W, H, spp, depth), spp)
     assert (got != ref).sum() <= 3 and np.abs(got - ref.astype(int)).max() <= 1
