@@ -143,6 +143,8 @@ int rt_last_kernel_ms(rt_scene*, float* ms_out);
  * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
  * that carried a live path ([2] / (64*[1]) = lane utilisation). */
 int rt_last_stats(rt_scene*, unsigned long long out3[3]);
+/* Diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections (zeros in a normal build). */
+int rt_debug_section_cycles(rt_scene*, unsigned long long out6[6]);
 /* Debug/parity aid: like rt_render but also returns every sample's radiance (W*H*spp*3 doubles). */
 int rt_render_samples(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
                       uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,

@@ -42,6 +42,7 @@ template <typename T> DEV V3<T> cross(V3<T> a, V3<T> b) { return mk<T>(a.y * b.z
 DEV double rsqrt_(double x) { return ::sqrt(x); }
 DEV float rsqrt_(float x) { return ::sqrtf(x); }
 template <typename T> DEV T length(V3<T> a) { return rsqrt_(dot(a, a)); }                                           // vec.rs:42-44
+
 template <typename T> DEV V3<T> normalized(V3<T> a) { return a / length(a); }                                       // vec.rs:56-58
 template <typename T> DEV T sq_of_len(V3<T> a) { T l = length(a); return l * l; }                                   // `.length().powi(2)`
 template <typename T> DEV T get(V3<T> v, uint32_t k) { return k == 0 ? v.x : (k == 1 ? v.y : v.z); }
@@ -741,7 +742,7 @@ static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-w
 #define DIAG_ADD(k) do {} while (0)
 #endif
 template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : 2)) pathtrace_kernel(const KParams<T> P) {
+__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : (FEATS == (F_BVH | F_TRIS) ? 3 : 2))) pathtrace_kernel(const KParams<T> P) {
     // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
@@ -1041,18 +1042,22 @@ static int occupancy_one(size_t shmem) {
     return nb;
 }
 
-// Three instantiations per arithmetic type: the lean one (rects + instances + Lambertian/Metal/DiffuseLight — everything
-// the Cornell box needs), the full one without the principled material, and the full one with it.
+// Four instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
+// Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
+// everything but the principled material, and everything (2 waves/SIMD).
 static const uint32_t FEATS_LEAN = 0u;
+static const uint32_t FEATS_MESH = F_BVH | F_TRIS;
 static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
 
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
     if ((scene_feats & ~FEATS_LEAN) == 0u) return launch_one<T, FEATS_LEAN>(P, n_blocks, shmem, stream);
+    if ((scene_feats & ~FEATS_MESH) == 0u) return launch_one<T, FEATS_MESH>(P, n_blocks, shmem, stream);
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) return launch_one<T, FEATS_NO_PBR>(P, n_blocks, shmem, stream);
     return launch_one<T, F_ALL>(P, n_blocks, shmem, stream);
 }
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, size_t shmem) {
     if ((scene_feats & ~FEATS_LEAN) == 0u) return occupancy_one<T, FEATS_LEAN>(shmem);
+    if ((scene_feats & ~FEATS_MESH) == 0u) return occupancy_one<T, FEATS_MESH>(shmem);
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) return occupancy_one<T, FEATS_NO_PBR>(shmem);
     return occupancy_one<T, F_ALL>(shmem);
 }

@@ -1,0 +1,17 @@
+"""Kernel time of the BASELINE workloads at reduced spp (same frame sizes): python tools/workloads_time.py [spp]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import torch
+from PIL import Image
+from raytracinginrust_amd import _lib, render as R, scenes, workloads
+be = _lib.load()
+im = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB'); earth = (im.tobytes(), *im.size)
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+for key in ('C1', 'C2', 'C3', 'C4'):
+    w = workloads.WORKLOADS[key]
+    b, cam, bg = workloads.build(w, be, earth)
+    s = min(spp, w.spp)
+    for _ in range(2):
+        out = R.render(b, cam, bg, w.W, w.H, s, w.max_depth)
+    ms = R.last_kernel_ms(b); st = R.last_stats(b)
+    print(f'{key} {w.scene} {w.W}x{w.H} at {s} spp: {ms:9.2f} ms  {w.W*w.H*s/ms/1e3:8.1f} Msamples/s  lane util {st["live_lane_iterations"]/(64*st["wave_iterations"]):.3f}  -> full config ({w.spp} spp) ~ {ms*w.spp/s/1e3:.2f} s')
