@@ -41,6 +41,21 @@ def cpu_baseline(w, sample_spp):
                       f"oracle f64, threads over rows)"}, orc.algorithmic_bytes_per_sample(cnt, sample_spp)
 
 
+def pmc_traffic_bytes(workload_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE and
+    WRITE_SIZE runs; counters are in KB; raw values — the accesses are 8-byte f64 atomics, for which the guide has no
+    correction).  None if no profile of this workload is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_bench_{workload_key}_pmc_summary.csv")))
+    if not files:
+        return None, None
+    vals = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(files[-1]))}
+    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
+        return None, None
+    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.basename(files[-1])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,8 +133,10 @@ def main():
         roof = None
         if bps is not None:
             achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
+            traffic, traffic_src = pmc_traffic_bytes(w.key) if (world == 1 and not args.f32) else (None, None)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": None, "kernel": "rt::pathtrace_kernel<double, 0>" if not args.f32 else "rt::pathtrace_kernel<float, 0>",
+                    "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": bps * local_samples, "kernel": "rt::pathtrace_kernel<double, 0>" if not args.f32 else "rt::pathtrace_kernel<float, 0>",
                     "kernel_ms": k_ms, "bytes_per_sample": bps,
                     "note": "algorithmic bytes (event x record-size model, SURVEY 8(d)); the scene is L2/LDS-resident, "
                             "physical HBM traffic is ~ the framebuffer (see DESIGN.md / profiles/)"}
