@@ -80,10 +80,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    # RT_BENCH_BACKEND=gloo lets the N > 1 flow be exercised with several ranks sharing one GPU (development boxes
+    # have a single GPU, and RCCL refuses two ranks on one device); the driver's runs use the default, nccl = RCCL.
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+    dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(backend)
 
     be = _lib.load()            # after `import torch`: one HIP runtime in the process
     w = workloads.WORKLOADS[args.workload]
@@ -113,7 +120,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     stats = R.last_stats(b)
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

@@ -41,11 +41,14 @@ def gather_frame(local: torch.Tensor, W: int, H: int, tile_px: int, dst: int = 0
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return assemble(local.unsqueeze(0), W, H, tile_px)
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, bufs, dst=dst)
+    staged = local
+    if local.is_cuda and dist.get_backend() == "gloo":      # gloo (CPU tests / single-GPU development) gathers host tensors
+        staged = local.cpu()
+    bufs = [torch.empty_like(staged) for _ in range(world)] if rank == dst else None
+    dist.gather(staged, bufs, dst=dst)
     if rank != dst:
         return None
-    return assemble(torch.stack(bufs, 0), W, H, tile_px)
+    return assemble(torch.stack(bufs, 0).to(local.device), W, H, tile_px)
 
 
 class TileRenderer:
