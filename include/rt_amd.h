@@ -113,6 +113,12 @@ void rt_format_color(const double rgb_sum[3], uint64_t samples_per_pixel, uint64
  * bottom.  rgb_sum is W*H*3 in output order (row 0 = top).  path NULL or "-" writes to stdout. */
 int rt_write_ppm(const char* path, const double* rgb_sum, uint32_t W, uint32_t H, uint64_t samples_per_pixel);
 
+/* Host asset ingest, `image::open(path).to_rgb8()` (src/main.rs:248,491): decodes a baseline JPEG (8-bit, grey or YCbCr,
+ * 1x1 sampling — the class of the reference's earthmap.jpg) held in memory into a malloc'ed interleaved RGB8 buffer
+ * (release with rt_free); NULL + rt_last_error() on anything else.  The result feeds rt_texture_image(). */
+uint8_t* rt_decode_jpeg_rgb8(const uint8_t* data, size_t size, uint32_t* width, uint32_t* height);
+void rt_free(void*);
+
 /* Flatten the Hittable tree into the device scene (no GPU needed); fills counts for inspection:
  * objects, ops, rects, spheres, moving spheres, triangles, bvh nodes, materials, textures, lights, media, perlins */
 int rt_scene_flatten(rt_scene*, uint32_t counts_out[12]);

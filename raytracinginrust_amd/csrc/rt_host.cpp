@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,8 @@
 #include "rt_launch.h"
 
 using namespace rt;
+
+namespace rt { bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height, std::string& err); }
 
 struct rt_scene { Scene s; };
 struct rt_rng { Rng r; };
@@ -241,6 +244,19 @@ int rt_write_ppm(const char* path, const double* rgb_sum, uint32_t W, uint32_t H
     if (f != stdout) std::fclose(f); else std::fflush(f);
     return 0;
 }
+
+// image::open(path).to_rgb8() for the reference's asset class (src/main.rs:248,491): baseline JPEG -> RGB8 (csrc/rt_jpeg.cpp)
+uint8_t* rt_decode_jpeg_rgb8(const uint8_t* data, size_t size, uint32_t* width, uint32_t* height) {
+    if (!data || !width || !height) { set_err("null argument"); return nullptr; }
+    std::vector<uint8_t> rgb; std::string err; uint32_t w = 0, h = 0;
+    if (!decode_jpeg_rgb8(data, size, rgb, w, h, err)) { set_err("image not found / not decodable: " + err); return nullptr; }
+    uint8_t* out = (uint8_t*)std::malloc(rgb.size());
+    if (!out) { set_err("out of memory"); return nullptr; }
+    std::memcpy(out, rgb.data(), rgb.size());
+    *width = w; *height = h;
+    return out;
+}
+void rt_free(void* p) { std::free(p); }
 
 int rt_scene_flatten(rt_scene* sc, uint32_t counts[12]) {
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iterator>
 #include <sstream>
 #include <string>
 #include "../../include/raytracinginrust.hpp"
@@ -218,13 +219,28 @@ static bool read_p6(const std::string& path, std::vector<uint8_t>& data, uint32_
     return (bool)f;
 }
 
+// image::open(path).to_rgb8() (main.rs:248,491): a baseline JPEG goes through the library's decoder, a P6 file is read directly
+static bool read_image(const std::string& path, std::vector<uint8_t>& data, uint32_t& w, uint32_t& h) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (bytes.size() > 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) {
+        uint8_t* rgb = rt_decode_jpeg_rgb8(bytes.data(), bytes.size(), &w, &h);
+        if (!rgb) { std::fprintf(stderr, "%s\n", rt_last_error()); return false; }
+        data.assign(rgb, rgb + (size_t)w * h * 3);
+        rt_free(rgb);
+        return true;
+    }
+    return read_p6(path, data, w, h);
+}
+
 enum class SceneKind { Random, TwoSphere, TwoPerlinSphere, Earth, LightRoom, CornellBox, CornellSmoke, CornellTest, FinalScene, Progress };   // src/main.rs:564-575
 
 int main(int argc, char** argv) {
     SceneKind scene = SceneKind::CornellBox;
     uint32_t image_width = 500, image_height = 500, samples_per_pixel = 800, max_depth = 100;    // main.rs:579-583
     uint64_t seed = 0x5EED; uint32_t flags = RT_F64;
-    std::string obj_path = "teapot.obj", earth_path = "earthmap.ppm";
+    std::string obj_path = "teapot.obj", earth_path = "earthmap.jpg";       // the reference's asset names (main.rs:248,491)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&]() -> const char* { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -269,7 +285,7 @@ int main(int argc, char** argv) {
             break;
         case SceneKind::Earth: {
             std::vector<uint8_t> tex; uint32_t ew = 0, eh = 0;
-            if (!read_p6(earth_path, tex, ew, eh)) throw Error("image not found: " + earth_path);      // main.rs:248
+            if (!read_image(earth_path, tex, ew, eh)) throw Error("image not found: " + earth_path);      // main.rs:248
             earth(s, tex, ew, eh);
             background = Color(0.7, 0.8, 1.0);
             camera = Camera::new_(Point3(13.0, 2.0, 3.0), Point3(0.0, 0.0, 0.0), vup, 20.0, aspect_ratio, 0.1, 10.0, 0.0, 1.0);
@@ -302,7 +318,7 @@ int main(int argc, char** argv) {
             break;
         case SceneKind::FinalScene: {
             std::vector<uint8_t> earth; uint32_t ew = 0, eh = 0;
-            if (!read_p6(earth_path, earth, ew, eh)) throw Error("image not found: " + earth_path);    // main.rs:491 .expect("image not found")
+            if (!read_image(earth_path, earth, ew, eh)) throw Error("image not found: " + earth_path);    // main.rs:491 .expect("image not found")
             final_scene(s, seed, earth, ew, eh);
             background = Color(0.0, 0.0, 0.0);
             camera = Camera::new_(Point3(478.0, 278.0, -600.0), Point3(278.0, 278.0, 0.0), vup, 40.0, aspect_ratio, 0.01, 10.0, 0.0, 1.0);

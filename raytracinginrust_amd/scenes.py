@@ -273,6 +273,29 @@ def cornell_test(backend: Backend, obj_path: str, aspect_ratio: float = 1.0, sca
     return b, cam, (0.0, 0.0, 0.0)
 
 
+def load_image_rgb8(path: str):
+    """`image::open(path).to_rgb8()` (src/main.rs:248,491) -> (bytes, width, height).  JPEG goes through the library's own
+    baseline decoder (csrc/rt_jpeg.cpp); PNG fixtures through Pillow."""
+    if path.lower().endswith((".jpg", ".jpeg")):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load().lib
+        lib.rt_decode_jpeg_rgb8.restype = C.c_void_p
+        lib.rt_decode_jpeg_rgb8.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.rt_free.argtypes = [C.c_void_p]
+        data = open(path, "rb").read()
+        w, h = C.c_uint32(), C.c_uint32()
+        ptr = lib.rt_decode_jpeg_rgb8(data, len(data), C.byref(w), C.byref(h))
+        if not ptr:
+            raise RuntimeError(lib.rt_last_error().decode())
+        out = C.string_at(ptr, 3 * w.value * h.value)
+        lib.rt_free(ptr)
+        return out, w.value, h.value
+    from PIL import Image
+    im = Image.open(path).convert("RGB")
+    return im.tobytes(), im.size[0], im.size[1]
+
+
 def asset_path(name: str) -> str:
     """Committed data fixtures (tests/golden/): the reference's assets cannot be read at run time."""
     return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", name)

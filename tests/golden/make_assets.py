@@ -17,3 +17,9 @@ assert im.size == (1024, 512)
 im.resize((256, 128), Image.BOX).save(os.path.join(here, "earthmap_256x128.png"), optimize=True)
 print("ok")
 
+
+# A baseline 4:4:4 JPEG of the same texels (the reference's earthmap.jpg is baseline, 8-bit, 1x1-sampled YCbCr): input for
+# the library's JPEG ingest test.  Encoded by Pillow from the fixture above; tests compare our decode with Pillow's.
+Image.open(os.path.join(here, "earthmap_256x128.png")).save(os.path.join(here, "earthmap_256x128_444.jpg"), quality=90, subsampling=0, optimize=False, progressive=False)
+Image.open(os.path.join(here, "earthmap_256x128.png")).convert("L").save(os.path.join(here, "earthmap_256x128_grey.jpg"), quality=85)
+print("ok jpeg")
