@@ -332,3 +332,19 @@ def test_cxx_host_main_prints_the_same_ppm(tmp_path, pbe, scene, depth):
     pb, pcam, pbg = build(pbe, aspect_ratio=W / H)
     ref = R.format_image(R.render(pb, pcam, pbg, W, H, spp, depth), spp)
     assert (got != ref).sum() <= 3 and np.abs(got - ref.astype(int)).max() <= 1
+
+
+def test_cxx_host_final_scene_with_jpeg_ingest(pbe):
+    """`rtrender --scene final --earth <baseline JPEG>`: the C++ host decodes the texture itself (image::open, main.rs:491),
+    draws the scene's random numbers in the reference's order (boxes, Perlin::new, spheres) and must print the image the
+    Python-built scene gives with the same decoded texels."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "host", "rtrender")
+    jpg = scenes.asset_path("earthmap_256x128_444.jpg")
+    W, H, spp, depth = 40, 40, 8, 20
+    txt = subprocess.run([exe, "--scene", "final", "--earth", jpg, "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", str(depth)],
+                         check=True, capture_output=True, text=True).stdout.split("\n")
+    got = np.array([[int(x) for x in l.split()] for l in txt[3:3 + W * H]]).reshape(H, W, 3)
+    pb, pcam, pbg = scenes.final_scene(pbe, *scenes.load_image_rgb8(jpg))
+    ref = R.format_image(R.render(pb, pcam, pbg, W, H, spp, depth), spp)
+    assert (got != ref).sum() <= 3 and np.abs(got - ref.astype(int)).max() <= 1
