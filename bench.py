@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--workload", default="C2")
     ap.add_argument("--tile-px", type=int, default=64)
     ap.add_argument("--f32", action="store_true", help="throughput variant (not the headline: reduced precision)")
+    ap.add_argument("--near-first", action="store_true", help="opt-in RT_NEAR_FIRST_BVH traversal (not the reference's order)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
         im = Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")
         earth = (im.tobytes(), im.size[0], im.size[1])
     b, cam, bg = workloads.build(w, be, earth)
-    flags = R.RT_F32 if args.f32 else R.RT_F64
+    flags = (R.RT_F32 if args.f32 else R.RT_F64) | (R.RT_NEAR_FIRST_BVH if args.near_first else 0)
     tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world)
 
     def sync():

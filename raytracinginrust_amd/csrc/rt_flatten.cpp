@@ -173,7 +173,8 @@ struct Flattener {
         for (int k = 0; k < 3; k++) { out_box.mn[k] = std::fmin(lb.mn[k], rb.mn[k]); out_box.mx[k] = std::fmax(lb.mx[k], rb.mx[k]); }   // aabb.rs:40-51
         DBvhNode<double>& nd = f.bvh[me];
         for (int k = 0; k < 3; k++) { nd.mn[k] = out_box.mn[k]; nd.mx[k] = out_box.mx[k]; }
-        nd.a = li;      // == me + 1
+        (void)li;                  // the left child is always me + 1 (preorder), so `a` carries the split axis instead:
+        nd.a = (uint32_t)axis;     // children were ordered by centroid along it (used only by the opt-in near-first traversal)
         nd.b = ri;
         return true;
     }

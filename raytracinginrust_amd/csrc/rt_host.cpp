@@ -393,7 +393,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     int dev = 0; HIP_OK(hipGetDevice(&dev));
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, dev));
     size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
-    int bpc = pathtrace_blocks_per_cu<T>(f.feats, shmem);
+    int bpc = pathtrace_blocks_per_cu<T>(f.feats, flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     uint64_t waves_needed = (n_local_px * spp + 63) / 64;
     uint64_t blocks_needed = (waves_needed + 3) / 4;

@@ -8,7 +8,7 @@
 //   object = wrapper chain ops[first_op .. first_op+n_ops) outermost first (Translate / Rotate / FlipNormal),
 //            optional ConstantMedium (outermost only), and one geometry:
 //              a typed range of primitives (1 rect, 6 rects = Cube, n triangles = Mesh list, ...) or a BVH root
-//   BVH    = nodes in DFS preorder: left child = node + 1, right child stored; leaves hold a typed
+//   BVH    = nodes in DFS preorder: left child = node + 1, right child + split axis stored; leaves hold a typed
 //            primitive range (a sphere, a moving sphere, a triangle, or a Cube's 6 rects)
 //   lights = light records (rect / sphere / "other" = trait default pdf 0, random (1,0,0))
 //
@@ -36,10 +36,12 @@ enum Feat : uint32_t {
     F_TEXTURES = 1u << 4,   // Check / Noise / Image textures
     F_DIELECTRIC = 1u << 5, // Dielectric material
     F_PBR = 1u << 6,        // principled material (PBR) + PDF::BRDF
-    F_ALL = 0x7F
+    F_ALL = 0x7F,
+    F_NEAR_FIRST = 1u << 7  // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
 };
 
-static const uint32_t BVH_LEAF = 0x80000000u;     // node.a: bit 31 leaf, bits 28..30 GeomKind, bits 0..27 first index
+static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count;
+                                                   // inner: node.a = split axis (0..2), node.b = right child, left child = node + 1
 static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
 static const int RT_MAX_BVH_DEPTH = 48;
 

@@ -21,6 +21,7 @@
 // functions (sin, cos, atan2, acos, log) may differ from a host libm in the last ulp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rt_ir.h"
 #include "rt_rng.h"
 #include "rt_launch.h"
@@ -244,6 +245,13 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
 // The recursion's t_max at any node equals min(original t_max, closest hit found earlier in DFS order), so one
 // running `closest` with an explicit stack (staged in LDS, one dword column per lane) is the same search.
 // AABB::hit (aabb.rs:19-36) recomputes 1/d per node; the value is the same every time, so it is hoisted.
+// In the reference's left-then-right order a later leaf with t <= t_max replaces an earlier one (hit.rs:62, bvh.rs:81-84).
+// When children are visited nearer-first (RT_NEAR_FIRST_BVH) the same winner is kept by letting an exact tie go to the leaf
+// that comes later in preorder (= later in the reference's DFS).
+template <typename T> DEV bool bvh_accept(bool near_first, T t, T closest, uint32_t leaf, uint32_t best_leaf) {
+    return !near_first || t < closest || !(t == closest) || leaf >= best_leaf;
+}
+
 // Plain traversal loop (one node per iteration): used when leaves are single cheap primitives (triangle meshes), where
 // holding leaves back only adds loop overhead (measured: the teapot room is 9 % faster with this form, the final scene —
 // cube and sphere leaves — 7.5 % faster with the while-while form below).
@@ -254,6 +262,8 @@ DEV bool bvh_hit_simple(const KParams<T>& P, uint32_t root, const RayT<T>& ray, 
     bool any = false;
     uint32_t node = root;
     uint32_t sp = 0;
+    const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;   // RT_NEAR_FIRST_BVH (opt-in), compile-time: no cost in the default mode
+    uint32_t best_leaf = 0;
     for (;;) {
         const DBvhNode<T> nd = ld_node(P.bvh + node);
         bool inside = true;
@@ -274,11 +284,13 @@ DEV bool bvh_hit_simple(const KParams<T>& P, uint32_t root, const RayT<T>& ray, 
         if (inside) {
             if (nd.a & BVH_LEAF) {
                 T t; uint32_t prim;
-                if (range_hit<T, FEATS>(P, (nd.a >> 28) & 7u, nd.a & 0x0FFFFFFFu, nd.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
+                if (range_hit<T, FEATS>(P, (nd.a >> 28) & 7u, nd.a & 0x0FFFFFFFu, nd.b, ray, t_min, closest, t, prim) &&
+                    bvh_accept(near_first, t, closest, node, best_leaf)) { closest = t; prim_out = prim; any = true; best_leaf = node; }
             } else {
-                stack[sp * 64u] = nd.b;     // right child waits; left child is the next node in preorder
+                const bool right_first = near_first && get(ray.d, nd.a) < T(0);
+                stack[sp * 64u] = right_first ? node + 1u : nd.b;      // the other child waits (reference order: right waits)
                 sp++;
-                node = nd.a;
+                node = right_first ? nd.b : node + 1u;
                 continue;
             }
         }
@@ -298,12 +310,14 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     const uint32_t DONE = 0xFFFFFFFFu;
     uint32_t node = root;
     uint32_t sp = 0;
+    const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;   // RT_NEAR_FIRST_BVH (opt-in), compile-time: no cost in the default mode
+    uint32_t best_leaf = 0;
     // "while-while" traversal: every lane first walks inner nodes until it holds a leaf to test (or has run out of nodes),
     // then the leaves are tested together.  A lane's own sequence of box tests, leaf tests and t_max updates is exactly
     // the recursion's (bbox, left, right); lanes merely wait for each other at the leaf step, which keeps the expensive
     // primitive tests from running with one or two lanes active.
     for (;;) {
-        uint32_t leaf_a = 0, leaf_b = 0;
+        uint32_t leaf_a = 0, leaf_b = 0, leaf_node = 0;
         bool have_leaf = false;
         while (node != DONE && !have_leaf) {
             const DBvhNode<T> nd = ld_node(P.bvh + node);
@@ -323,19 +337,21 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                 }
             }
             if (inside && !(nd.a & BVH_LEAF)) {
-                stack[sp * 64u] = nd.b;     // right child waits; left child is the next node in preorder
+                const bool right_first = near_first && get(ray.d, nd.a) < T(0);
+                stack[sp * 64u] = right_first ? node + 1u : nd.b;      // the other child waits (reference order: right waits)
                 sp++;
-                node = nd.a;
+                node = right_first ? nd.b : node + 1u;
                 continue;
             }
-            if (inside) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; }
+            if (inside) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; leaf_node = node; }
             // this node is finished (culled, or a leaf now pending): the next one comes off the stack
             if (sp == 0) node = DONE;
             else { sp--; node = stack[sp * 64u]; }
         }
         if (have_leaf) {
             T t; uint32_t prim;
-            if (range_hit<T, FEATS>(P, (leaf_a >> 28) & 7u, leaf_a & 0x0FFFFFFFu, leaf_b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
+            if (range_hit<T, FEATS>(P, (leaf_a >> 28) & 7u, leaf_a & 0x0FFFFFFFu, leaf_b, ray, t_min, closest, t, prim) &&
+                bvh_accept(near_first, t, closest, leaf_node, best_leaf)) { closest = t; prim_out = prim; any = true; best_leaf = leaf_node; }
         }
         if (node == DONE) break;          // this lane is finished (it had at most its last leaf above)
     }
@@ -804,7 +820,7 @@ static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-w
 #define DIAG_ADD(k) do {} while (0)
 #endif
 template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : (FEATS == (F_BVH | F_TRIS) ? 3 : 2))) pathtrace_kernel(const KParams<T> P) {
+__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & ~F_NEAR_FIRST) == (F_BVH | F_TRIS) ? 3 : 2))) pathtrace_kernel(const KParams<T> P) {
     // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
@@ -1104,29 +1120,30 @@ static int occupancy_one(size_t shmem) {
     return nb;
 }
 
-// Four instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
+// Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
 // Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
-// everything but the principled material, and everything (2 waves/SIMD).
+// everything but the principled material, and everything (2 waves/SIMD); the BVH ones also with near-first traversal.
 static const uint32_t FEATS_LEAN = 0u;
 static const uint32_t FEATS_MESH = F_BVH | F_TRIS;
 static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
 
-template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
-    if ((scene_feats & ~FEATS_LEAN) == 0u) return launch_one<T, FEATS_LEAN>(P, n_blocks, shmem, stream);
-    if ((scene_feats & ~FEATS_MESH) == 0u) return launch_one<T, FEATS_MESH>(P, n_blocks, shmem, stream);
-    if ((scene_feats & ~FEATS_NO_PBR) == 0u) return launch_one<T, FEATS_NO_PBR>(P, n_blocks, shmem, stream);
-    return launch_one<T, F_ALL>(P, n_blocks, shmem, stream);
+template <typename T, typename F> static auto dispatch(uint32_t scene_feats, bool near_first, F&& f) {
+    const bool nf = near_first && (scene_feats & F_BVH);
+    if ((scene_feats & ~FEATS_LEAN) == 0u) return f(std::integral_constant<uint32_t, FEATS_LEAN>());
+    if ((scene_feats & ~FEATS_MESH) == 0u) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
+    if ((scene_feats & ~FEATS_NO_PBR) == 0u) return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
+    return nf ? f(std::integral_constant<uint32_t, F_ALL | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, F_ALL>());
 }
-template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, size_t shmem) {
-    if ((scene_feats & ~FEATS_LEAN) == 0u) return occupancy_one<T, FEATS_LEAN>(shmem);
-    if ((scene_feats & ~FEATS_MESH) == 0u) return occupancy_one<T, FEATS_MESH>(shmem);
-    if ((scene_feats & ~FEATS_NO_PBR) == 0u) return occupancy_one<T, FEATS_NO_PBR>(shmem);
-    return occupancy_one<T, F_ALL>(shmem);
+template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
+    return dispatch<T>(scene_feats, (P.flags & 8u) != 0u, [&](auto feats) { return launch_one<T, decltype(feats)::value>(P, n_blocks, shmem, stream); });
+}
+template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem) {
+    return dispatch<T>(scene_feats, (flags & 8u) != 0u, [&](auto feats) { return occupancy_one<T, decltype(feats)::value>(shmem); });
 }
 
 template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);
 template hipError_t launch_pathtrace<float>(const KParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
-template int pathtrace_blocks_per_cu<double>(uint32_t, size_t);
-template int pathtrace_blocks_per_cu<float>(uint32_t, size_t);
+template int pathtrace_blocks_per_cu<double>(uint32_t, uint32_t, size_t);
+template int pathtrace_blocks_per_cu<float>(uint32_t, uint32_t, size_t);
 
 } // namespace rt

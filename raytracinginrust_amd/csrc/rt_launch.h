@@ -9,5 +9,5 @@ static const size_t RT_REGEN_LDS_BYTES = 4u * (7u * 64u * 8u + 6u * 64u * 4u);
 // Launch the persistent path-tracing kernel: n_blocks blocks of 256 threads, `shmem` bytes of LDS for BVH stacks.
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
 // Resident blocks per CU for the instantiation that serves `scene_feats`.
-template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, size_t shmem);
+template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem);
 }

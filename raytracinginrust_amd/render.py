@@ -12,7 +12,7 @@ import numpy as np
 from . import _lib
 from .api import CameraParams, SceneBuilder
 
-RT_F64, RT_F32, RT_STOP_ON_ZERO, RT_ISOTROPIC_SCATTER = 0, 1, 2, 4
+RT_F64, RT_F32, RT_STOP_ON_ZERO, RT_ISOTROPIC_SCATTER, RT_NEAR_FIRST_BVH = 0, 1, 2, 4, 8
 FLATTEN_COUNT_NAMES = ("objects", "ops", "rects", "spheres", "moving_spheres", "triangles", "bvh_nodes",
                        "materials", "textures", "lights", "media", "perlins")
 

@@ -253,6 +253,19 @@ def test_remaining_reference_scenes(pbe, obe, orc_mod, earth, name, scatter):
         assert got.mean() > absorb.mean()              # scattering media return light that absorbing media swallow
 
 
+@pytest.mark.parametrize("name", ["random", "final", "teapot"])
+def test_near_first_bvh_mode_gives_the_same_samples(name, pbe, obe, orc_mod, earth):
+    """RT_NEAR_FIRST_BVH (opt-in) visits the nearer child first; the closest hit — and therefore every sample — is the
+    reference's, ties included (resolved by preorder).  Checked against the oracle, not just against the default mode."""
+    W, H, spp, depth = CASES[name]
+    ob, ocam, obg = build_scene(name, obe, earth)
+    pb, pcam, pbg = build_scene(name, pbe, earth)
+    ref, rs = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
+    got, gs = R.render(pb, pcam, pbg, W, H, spp, depth, want_samples=True, flags=R.RT_NEAR_FIRST_BVH)
+    n_bad, _, _ = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED
+
+
 def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
     b, cam, bg = _cornell(pbe)
     a = R.render(b, cam, bg, 64, 64, 32, 50)

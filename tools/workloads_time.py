@@ -11,7 +11,8 @@ for key in ('C1', 'C2', 'C3', 'C4'):
     w = workloads.WORKLOADS[key]
     b, cam, bg = workloads.build(w, be, earth)
     s = min(spp, w.spp)
+    flags = int(os.environ.get('RT_FLAGS', '0'))
     for _ in range(2):
-        out = R.render(b, cam, bg, w.W, w.H, s, w.max_depth)
+        out = R.render(b, cam, bg, w.W, w.H, s, w.max_depth, flags=flags)
     ms = R.last_kernel_ms(b); st = R.last_stats(b)
     print(f'{key} {w.scene} {w.W}x{w.H} at {s} spp: {ms:9.2f} ms  {w.W*w.H*s/ms/1e3:8.1f} Msamples/s  lane util {st["live_lane_iterations"]/(64*st["wave_iterations"]):.3f}  -> full config ({w.spp} spp) ~ {ms*w.spp/s/1e3:.2f} s')
