@@ -203,9 +203,8 @@ struct Flattener {
             // HittableList::hit (hit.rs:59-71) keeps the closest hit, later items winning ties, and wrappers
             // act per hit, so Wrapper(List[a,b]) == List[Wrapper(a), Wrapper(b)].  A ConstantMedium boundary
             // is different (two boundary queries, medium.rs:29-30) and must stay one object.
-            if (medium >= 0 && h.items.size() != 1) {
-                // a homogeneous run of bare prims can still be one typed range
-            }
+            // (As a medium boundary a list must flatten to exactly one object: one wrapped item, or a homogeneous run of
+            // bare primitives such as a Mesh's triangles, which becomes one typed range.)
             size_t i = 0;
             bool emitted_any = false;
             while (i < h.items.size()) {
@@ -227,7 +226,8 @@ struct Flattener {
                     i++;
                 }
             }
-            if (medium >= 0 && !emitted_any) return fail("ConstantMedium boundary is an empty list");
+            // an empty boundary list never reports a hit (hit.rs:59-71), so such a medium never scatters and draws nothing
+            // (medium.rs:29): emitting no object at all is the same thing
             return true;
         }
         case HNode::FLIP: case HNode::TRANSLATE: case HNode::ROTATE: {
