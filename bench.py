@@ -24,13 +24,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def cpu_baseline(w, sample_spp):
+def cpu_baseline(w, sample_spp, earth=None):
     """CPU restatement of the reference (oracle/), all host threads, on the workload's own pixel grid at
     `sample_spp` samples per pixel.  Also returns the oracle's algorithmic bytes/sample for this workload."""
     from oracle import orc
     from raytracinginrust_amd import workloads
     be = orc.load()
-    b, cam, bg = workloads.build(w, be)
+    b, cam, bg = workloads.build(w, be, earth)
     threads = min(orc.hardware_threads(), len(os.sched_getaffinity(0)))      # the cores this process may actually use
     t = time.perf_counter()
     _, cnt = orc.render(b, cam, bg, w.W, w.H, sample_spp, w.max_depth, want_counters=True, nthreads=threads, mode=0)
@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2")
-    ap.add_argument("--tile-px", type=int, default=64)
+    ap.add_argument("--tile-px", type=int, default=67, help="pixels per tile; prime by default (see dist.DEFAULT_TILE_PX)")
     ap.add_argument("--f32", action="store_true", help="throughput variant (not the headline: reduced precision)")
     ap.add_argument("--near-first", action="store_true", help="opt-in RT_NEAR_FIRST_BVH traversal (not the reference's order)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample (0 = skip)")
@@ -132,7 +132,7 @@ def main():
         value = w.samples * args.steps / elapsed / 1e6
         cpu, bps = None, workloads.BYTES_PER_SAMPLE.get(w.key)
         if world == 1 and args.cpu_spp > 0 and not args.f32:
-            cpu, bps = cpu_baseline(w, args.cpu_spp)
+            cpu, bps = cpu_baseline(w, args.cpu_spp, earth)
         k_ms = sum(kernel_ms) / len(kernel_ms)
         n_px = w.W * w.H                     # real (unpadded) pixels rank 0's launch owns
         local_px = sum(max(0, min(n_px, (t + 1) * args.tile_px) - t * args.tile_px)
@@ -144,7 +144,7 @@ def main():
             traffic, traffic_src = pmc_traffic_bytes(w.key) if (world == 1 and not args.f32) else (None, None)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": bps * local_samples, "kernel": "rt::pathtrace_kernel<double, 0>" if not args.f32 else "rt::pathtrace_kernel<float, 0>",
+                    "algorithmic_bytes_per_launch": bps * local_samples, "kernel": f"rt::pathtrace_kernel<{'float' if args.f32 else 'double'}, FEATS> (FEATS = 0 for the Cornell box; the leanest instantiation covering the scene)",
                     "kernel_ms": k_ms, "bytes_per_sample": bps,
                     "note": "algorithmic bytes (event x record-size model, SURVEY 8(d)); the scene is L2/LDS-resident, "
                             "physical HBM traffic is ~ the framebuffer (see DESIGN.md / profiles/)"}

@@ -361,3 +361,25 @@ def test_cxx_host_final_scene_with_jpeg_ingest(pbe):
     pb, pcam, pbg = scenes.final_scene(pbe, *scenes.load_image_rgb8(jpg))
     ref = R.format_image(R.render(pb, pcam, pbg, W, H, spp, depth), spp)
     assert (got != ref).sum() <= 3 and np.abs(got - ref.astype(int)).max() <= 1
+
+
+def test_4k_frame_index_ranges(pbe):
+    """BASELINE config 5's frame (3840x2160 = 8.3 M pixels; pixels x spp exceeds 2^32 at its 8192 spp): the 64-bit work
+    arithmetic at that frame size with a small spp.  Sharded as on 8 GPUs (prime tile size, see dist.py) the assembled
+    frame must equal the unsharded render, and the per-rank shares must be balanced."""
+    import torch
+    b, cam, bg = scenes.cornell_box(pbe, aspect_ratio=3840 / 2160)
+    W, H, spp, depth = 3840, 2160, 4, 50
+    full = R.render(b, cam, bg, W, H, spp, depth)
+    assert R.last_stats(b)["nonfinite_samples"] == 0
+    parts, means = [], []
+    for rank in range(8):
+        tr = D.TileRenderer(b, cam, bg, W, H, spp, depth, rank=rank, world=8)
+        parts.append(tr.render_local().clone())
+        means.append(float(parts[-1].mean().item()))
+    torch.cuda.synchronize()
+    frame = D.assemble(torch.stack(parts, 0), W, H, D.DEFAULT_TILE_PX).cpu().numpy()
+    assert np.all(np.abs(frame - full) <= 1e-12 * (spp + np.abs(full)))
+    assert max(means) / min(means) < 1.03                  # no aliasing between tile columns and ranks
+    small = R.render(b, cam, bg, W // 8, H // 8, 64, depth)
+    assert full.mean() / spp == pytest.approx(small.mean() / 64, rel=0.05)
