@@ -820,7 +820,7 @@ static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-w
 #define DIAG_ADD(k) do {} while (0)
 #endif
 template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & ~F_NEAR_FIRST) == (F_BVH | F_TRIS) ? 3 : 2))) pathtrace_kernel(const KParams<T> P) {
+__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 : 3))) pathtrace_kernel(const KParams<T> P) {
     // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
@@ -1122,7 +1122,8 @@ static int occupancy_one(size_t shmem) {
 
 // Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
 // Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
-// everything but the principled material, and everything (2 waves/SIMD); the BVH ones also with near-first traversal.
+// everything but the principled material (3 waves/SIMD with some spilling: measured 6 % faster on the final scene than
+// 2 waves/SIMD without), and everything (2 waves/SIMD); the BVH ones also with near-first traversal.
 static const uint32_t FEATS_LEAN = 0u;
 static const uint32_t FEATS_MESH = F_BVH | F_TRIS;
 static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
