@@ -2,18 +2,18 @@
 // for gfx950 (MI355X).  Replaces src/main.rs:772-833 (+ everything ray_color reaches).
 //
 // Shape of the kernel (not a translation of the reference's rayon loop):
-//   * work unit = one camera path (pixel, sample).  A wavefront (64 lanes) pulls whole pixels from a global
-//     queue (one atomic per chunk) and hands samples to its lanes.  Whenever lanes' paths end (miss, light,
-//     absorbed, depth), `__ballot` + `mbcnt` prefix ranks give every dead lane the next sample index
-//     ("compaction by regeneration"): the wave never drains between pixels, lanes stay full until the
-//     queue is empty.
-//   * the reference's recursion `e + w * ray_color(child)` (src/main.rs:41-120) is linear, so it runs as an
-//     in-kernel bounce loop carrying the throughput `beta`; radiance is added when the path terminates.
-//   * top-level objects (HittableList push order) are walked with wave-uniform indices -> scalar loads, no
-//     VGPR cost; only (t, object, primitive) of the closest hit is kept and the hit record is rebuilt once
-//     per bounce with per-lane gathers.  BVH traversal is per-lane with its stack staged in LDS.
-//   * per-pixel sums stay in registers (one accumulator per lane) and are combined with a segmented
-//     wave reduction when a lane moves to another pixel; one owner wave per pixel, so no float atomics.
+//   * work unit = one camera path (pixel, sample).  A wavefront (64 lanes) pulls work chunks from a global queue (one atomic
+//     per chunk: whole pixels for the bulk of the frame, 256-sample pieces for its tail) and generates the chunk's camera
+//     paths 64 at a time, every lane busy, into a per-wave LDS queue.  Whenever lanes' paths end (miss, light, absorbed,
+//     depth), `__ballot` + `mbcnt` prefix ranks let every dead lane pop the next queued path ("compaction by
+//     regeneration"): the wave never drains between pixels, lanes stay full until the queue is empty.
+//   * the reference's recursion `e + w * ray_color(child)` (src/main.rs:41-120) is linear, so it runs as an in-kernel
+//     bounce loop carrying the throughput `beta`; radiance is added when the path terminates.
+//   * top-level objects (HittableList push order) are walked with wave-uniform indices through the constant address
+//     space -> scalar loads, no VGPR cost; only (t, object, primitive) of the closest hit is kept and the hit record is
+//     rebuilt once per bounce with per-lane gathers.  BVH traversal is per-lane with its stack staged in LDS.
+//   * per-pixel sums stay in registers (one accumulator per lane); when a lane moves to another pixel the partial sums of
+//     one pixel are combined by a masked wave butterfly and added to the frame with one hardware f64 atomic per channel.
 //   * no MFMA: there is no dense contraction anywhere on this path.
 //
 // Arithmetic follows the reference expression by expression (cited inline) and is compiled with
