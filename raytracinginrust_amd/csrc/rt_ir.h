@@ -45,13 +45,15 @@ static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | Geo
 static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
 static const int RT_MAX_BVH_DEPTH = 48;
 
-template <typename T> struct DRect { T a0, a1, b0, b1, k; uint32_t plane, mat; };            // src/rect.rs:16-24
-template <typename T> struct DSphere { T c[3], r; uint32_t mat, pad; };                       // src/sphere.rs:38-43
-template <typename T> struct DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
-template <typename T> struct DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
+// Records are 16-byte aligned (the BVH node a whole 64 / 32 bytes) so that a per-lane fetch is a few 16-byte loads inside one
+// cache line instead of a string of 8-byte loads straddling two.
+template <typename T> struct alignas(16) DRect { T a0, a1, b0, b1, k; uint32_t plane, mat; };            // src/rect.rs:16-24
+template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad; };                       // src/sphere.rs:38-43
+template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
+template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct DOp { uint32_t kind, axis; T x, y, z; };                         // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
 struct DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
-template <typename T> struct DBvhNode { T mn[3], mx[3]; uint32_t a, b; };                     // f64: 56 B -> padded to 64
+template <typename T> struct alignas(8 * sizeof(T)) DBvhNode { T mn[3], mx[3]; uint32_t a, b; };     // f64: 64 B = one line per fetch; f32: 32 B
 template <typename T> struct DMaterial { uint32_t kind, tex; T albedo[3]; T param; };         // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
 template <typename T> struct DTexture { uint32_t kind, a, b, c; T color[3]; T scale; };       // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height

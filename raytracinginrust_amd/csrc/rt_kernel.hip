@@ -54,13 +54,28 @@ template <typename T> DEV V3<T> ld3(const T* p) { return mk<T>(p[0], p[1], p[2])
 #define CAS __attribute__((address_space(4)))
 template <typename F> DEV F cl(const F* p) { return *(const CAS F*)p; }
 template <typename T> DEV V3<T> cl3(const T* p) { return mk<T>(cl(p), cl(p + 1), cl(p + 2)); }
+// Whole-record fetch of a 16-byte-aligned POD record as 16-byte (then 8 / 4-byte) pieces through the constant address space.
+template <typename R> DEV R ld_record(const R* p) {
+    static_assert(alignof(R) >= 16 && sizeof(R) % 4 == 0, "record must be 16-byte aligned");
+    R r;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    constexpr size_t N = sizeof(R);
+    const char* src = (const char*)p; char* dst = (char*)&r;
+    size_t off = 0;
+#pragma unroll
+    for (; off + 16 <= N; off += 16) *(u4*)(dst + off) = *(const CAS u4*)(src + off);
+    if (off + 8 <= N) { *(u2*)(dst + off) = *(const CAS u2*)(src + off); off += 8; }
+    if (off + 4 <= N) { *(uint32_t*)(dst + off) = *(const CAS uint32_t*)(src + off); }
+    return r;
+}
 template <typename T> DEV DRect<T> ld_rect(const DRect<T>* p) { DRect<T> r; r.a0 = cl(&p->a0); r.a1 = cl(&p->a1); r.b0 = cl(&p->b0); r.b1 = cl(&p->b1); r.k = cl(&p->k); r.plane = cl(&p->plane); r.mat = cl(&p->mat); return r; }
-template <typename T> DEV DSphere<T> ld_sphere(const DSphere<T>* p) { DSphere<T> r; r.c[0] = cl(&p->c[0]); r.c[1] = cl(&p->c[1]); r.c[2] = cl(&p->c[2]); r.r = cl(&p->r); r.mat = cl(&p->mat); r.pad = 0; return r; }
-template <typename T> DEV DMSphere<T> ld_msphere(const DMSphere<T>* p) { DMSphere<T> r; for (int k = 0; k < 3; k++) { r.c0[k] = cl(&p->c0[k]); r.c1[k] = cl(&p->c1[k]); } r.t0 = cl(&p->t0); r.t1 = cl(&p->t1); r.r = cl(&p->r); r.mat = cl(&p->mat); r.pad = 0; return r; }
-template <typename T> DEV DTri<T> ld_tri(const DTri<T>* p) { DTri<T> r; for (int k = 0; k < 3; k++) { r.v0[k] = cl(&p->v0[k]); r.e1[k] = cl(&p->e1[k]); r.e2[k] = cl(&p->e2[k]); } r.mat = cl(&p->mat); r.pad = 0; return r; }
+template <typename T> DEV DSphere<T> ld_sphere(const DSphere<T>* p) { return ld_record(p); }
+template <typename T> DEV DMSphere<T> ld_msphere(const DMSphere<T>* p) { return ld_record(p); }
+template <typename T> DEV DTri<T> ld_tri(const DTri<T>* p) { return ld_record(p); }
 template <typename T> DEV DOp<T> ld_op(const DOp<T>* p) { DOp<T> r; r.kind = cl(&p->kind); r.axis = cl(&p->axis); r.x = cl(&p->x); r.y = cl(&p->y); r.z = cl(&p->z); return r; }
 DEV DObject ld_obj(const DObject* p) { DObject r; r.geom_kind = cl(&p->geom_kind); r.geom_first = cl(&p->geom_first); r.geom_count = cl(&p->geom_count); r.first_op = cl(&p->first_op); r.n_ops = cl(&p->n_ops); r.medium = cl(&p->medium); r.pad0 = r.pad1 = 0; return r; }
-template <typename T> DEV DBvhNode<T> ld_node(const DBvhNode<T>* p) { DBvhNode<T> r; for (int k = 0; k < 3; k++) { r.mn[k] = cl(&p->mn[k]); r.mx[k] = cl(&p->mx[k]); } r.a = cl(&p->a); r.b = cl(&p->b); return r; }
+template <typename T> DEV DBvhNode<T> ld_node(const DBvhNode<T>* p) { return ld_record(p); }
 template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r; r.kind = cl(&p->kind); r.tex = cl(&p->tex); for (int k = 0; k < 3; k++) r.albedo[k] = cl(&p->albedo[k]); r.param = cl(&p->param); return r; }
 template <typename T> DEV DPbr<T> ld_pbr(const DPbr<T>* p) { DPbr<T> r; r.metallic = cl(&p->metallic); r.subsurface = cl(&p->subsurface); r.specular = cl(&p->specular); r.roughness = cl(&p->roughness); r.specular_tint = cl(&p->specular_tint); r.anisotropic = cl(&p->anisotropic); r.sheen = cl(&p->sheen); r.sheen_tint = cl(&p->sheen_tint); r.clearcoat = cl(&p->clearcoat); r.clearcoat_gloss = cl(&p->clearcoat_gloss); return r; }
 template <typename T> DEV DTexture<T> ld_tex(const DTexture<T>* p) { DTexture<T> r; r.kind = cl(&p->kind); r.a = cl(&p->a); r.b = cl(&p->b); r.c = cl(&p->c); for (int k = 0; k < 3; k++) r.color[k] = cl(&p->color[k]); r.scale = cl(&p->scale); return r; }
