@@ -146,6 +146,9 @@ int rt_render_device(rt_scene*, const rt_camera*, const double background[3], ui
                      uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
                      uint32_t tile_px, uint32_t rank, uint32_t world_size,
                      void* d_out, size_t d_out_bytes, void* hip_stream);
+/* Optional: do now what the first render of this scene would do once inside its call (flatten, upload for the precision in
+ * `flags`, load the kernel's code object).  Launches nothing. */
+int rt_scene_prepare(rt_scene*, uint32_t flags);
 /* Milliseconds of the most recent path-tracing kernel launched by this library on this thread's scene,
  * from HIP events recorded on the launch stream (blocks until that kernel finishes). */
 int rt_last_kernel_ms(rt_scene*, float* ms_out);

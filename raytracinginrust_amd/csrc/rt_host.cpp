@@ -447,6 +447,26 @@ int rt_render_device(rt_scene* sc, const rt_camera* cam, const double bg[3], uin
     return render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, nullptr, (hipStream_t)hip_stream);
 }
 
+// One-time work a first render would otherwise do inside its call: flatten, upload the tables for the chosen precision,
+// create events / scratch words, and make the runtime load the kernel's code object (occupancy query).  No kernel is launched.
+int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
+    if (!sc) return set_err("null argument");
+    if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    Scene& s = sc->s;
+    if (flags & RT_F32) { if (ensure_uploaded<float>(s, s.dev32)) return -1; }
+    else { if (ensure_uploaded<double>(s, s.dev64)) return -1; }
+    if (!s.d_queue) HIP_OK(hipMalloc(&s.d_queue, 64));
+    if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 128));
+    if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
+    if (!s.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_stop = e; }
+    size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * s.flat.bvh_depth * 64 * sizeof(uint32_t);
+    int bpc = (flags & RT_F32) ? pathtrace_blocks_per_cu<float>(s.flat.feats, flags, shmem) : pathtrace_blocks_per_cu<double>(s.flat.feats, flags, shmem);
+    if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
+    HIP_OK(hipDeviceSynchronize());
+    return 0;
+}
+
 int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
     if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
     HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));

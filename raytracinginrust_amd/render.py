@@ -38,6 +38,13 @@ def flatten(b: SceneBuilder) -> dict:
     return dict(zip(FLATTEN_COUNT_NAMES, [int(x) for x in counts]))
 
 
+def prepare(b: SceneBuilder, flags: int = RT_F64) -> None:
+    """Flatten, upload and load the kernel now instead of inside the first render (no launch)."""
+    be = _lib.load()
+    if be.lib.rt_scene_prepare(b.h, flags) != 0:
+        raise RenderError(_err(be))
+
+
 def render(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int,
            seed: int = 0x5EED, flags: int = RT_F64, want_samples: bool = False):
     """Per-pixel sums of ray_color over `spp` samples, shape (H, W, 3) f64, row 0 = top (what `.sum()`

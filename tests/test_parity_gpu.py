@@ -266,6 +266,17 @@ def test_near_first_bvh_mode_gives_the_same_samples(name, pbe, obe, orc_mod, ear
     assert n_bad <= MAX_DIVERGED
 
 
+def test_prepare_does_not_change_the_render(pbe):
+    from raytracinginrust_amd import scenes
+    b1, cam, bg = scenes.cornell_box(pbe)
+    b2, _, _ = scenes.cornell_box(pbe)
+    R.prepare(b2)
+    R.prepare(b2, R.RT_F32)
+    assert np.array_equal(R.render(b1, cam, bg, 24, 24, 4, 8, seed=3), R.render(b2, cam, bg, 24, 24, 4, 8, seed=3))
+    with pytest.raises(R.RenderError):
+        R.prepare(SceneBuilder(pbe))                     # no world set
+
+
 def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
     b, cam, bg = _cornell(pbe)
     a = R.render(b, cam, bg, 64, 64, 32, 50)

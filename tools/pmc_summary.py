@@ -5,6 +5,7 @@ res = collections.OrderedDict()
 for f in sorted(glob.glob(os.path.join(root, '*', '*', '*counter_collection.csv'))):
     for r in csv.DictReader(open(f)):
         if 'pathtrace' not in r['Kernel_Name']: continue
+        if int(r.get('Grid_Size', r.get('Grid_Size_X', '1000000')) or 1000000) < 65536: continue      # ignore tiny auxiliary launches
         res.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
 out = []
 for k, v in res.items():
