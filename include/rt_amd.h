@@ -45,6 +45,10 @@ enum {
                               of the reference's always-left-first (src/bvh.rs:81-84).  Same closest hit; exact-t ties are
                               still resolved by the reference's DFS order.  Can differ only where a last-ulp box cull depends
                               on the order hits are found.                                                                   */
+    RT_PERSISTENT_BVH = 16, /* scheduling only, same samples: lanes keep their place inside a BVH while the rest of the wavefront
+                              shades / regenerates (mesh kernels).  Chosen automatically for a triangle-mesh BVH that stands
+                              beside other top-level objects (most rays never enter it); this flag forces it on ...            */
+    RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
                               old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };
@@ -156,6 +160,9 @@ int rt_last_kernel_ms(rt_scene*, float* ms_out);
  * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
  * that carried a live path ([2] / (64*[1]) = lane utilisation). */
 int rt_last_stats(rt_scene*, unsigned long long out3[3]);
+/* Scenes with a BVH (persistent-traversal kernel): [0] advance passes, [1] lanes taking part in them, [2] traversal
+ * steps, [3] lanes stepping, all summed over wavefronts ([3] / (64*[2]) = lane utilisation of the traversal). */
+int rt_last_traversal_stats(rt_scene*, unsigned long long out4[4]);
 /* Diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections (zeros in a normal build). */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out6[6]);
 /* Debug/parity aid: like rt_render but also returns every sample's radiance (W*H*spp*3 doubles). */

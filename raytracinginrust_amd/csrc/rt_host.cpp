@@ -347,6 +347,20 @@ template <typename T> DeviceScene<T>& dev_of(Scene& s);
 template <> DeviceScene<double>& dev_of<double>(Scene& s) { return s.dev64; }
 template <> DeviceScene<float>& dev_of<float>(Scene& s) { return s.dev32; }
 
+// Loop shape for mesh scenes (same samples either way): a triangle-mesh BVH that stands beside other top-level objects is
+// entered by a minority of the rays, which is where persistent traversal pays (measured +20 % on the teapot room); when
+// every ray walks the BVH (the BVH is the world) the lock-step loop is faster.
+static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
+    uint32_t out = flags;
+    if (!(flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) && (f.feats & F_BVH) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) == 0u) {
+        size_t n_bvh_objects = 0;
+        for (const DObject& ob : f.objects) n_bvh_objects += ob.geom_kind == G_BVH ? 1u : 0u;
+        if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size()) out |= RT_PERSISTENT_BVH;
+    }
+    if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
+    return out;
+}
+
 template <typename T>
 int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                 uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
@@ -371,9 +385,15 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         P.cam.cu[k] = (T)cam.cu[k]; P.cam.cv[k] = (T)cam.cv[k]; P.background[k] = (T)bg[k];
     }
     P.cam.lens_radius = (T)cam.lens_radius; P.cam.time0 = (T)cam.time0; P.cam.time1 = (T)cam.time1;
-    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = flags;
+    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = effective_flags(f, flags);
     P.tile_px = tile_px; P.rank = rank; P.world = world;
     P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
+    P.trav_hi = 48u; P.trav_lo = 32u; P.trav_leaf = 16u;      // measured best on the teapot room (tools/workloads_time.py sweeps)
+    if (const char* e = std::getenv("RT_AMD_TRAV_LEAF")) P.trav_leaf = (uint32_t)std::atoi(e);
+    if (const char* e = std::getenv("RT_AMD_TRAV_HI")) P.trav_hi = (uint32_t)std::atoi(e);      // tuning knobs (tools/ only)
+    if (const char* e = std::getenv("RT_AMD_TRAV_LO")) P.trav_lo = (uint32_t)std::atoi(e);
+    if (P.trav_hi < 1u) P.trav_hi = 1u; if (P.trav_hi > 64u) P.trav_hi = 64u;
+    if (P.trav_lo < 1u) P.trav_lo = 1u; if (P.trav_lo > P.trav_hi) P.trav_lo = P.trav_hi;
     uint64_t n_local_px = (uint64_t)P.n_local_tiles * tile_px;
     if (n_local_px >= 0xFFFFFFFFull) return set_err("too many local pixels");
     if ((size_t)n_local_px * 3 * sizeof(double) > d_out_bytes) return set_err("output buffer too small for n_local_tiles * tile_px * 3 doubles");
@@ -393,7 +413,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     int dev = 0; HIP_OK(hipGetDevice(&dev));
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, dev));
     size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
-    int bpc = pathtrace_blocks_per_cu<T>(f.feats, flags, shmem);
+    int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     uint64_t waves_needed = (n_local_px * spp + 63) / 64;
     uint64_t blocks_needed = (waves_needed + 3) / 4;
@@ -461,7 +481,8 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
     if (!s.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_stop = e; }
     size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * s.flat.bvh_depth * 64 * sizeof(uint32_t);
-    int bpc = (flags & RT_F32) ? pathtrace_blocks_per_cu<float>(s.flat.feats, flags, shmem) : pathtrace_blocks_per_cu<double>(s.flat.feats, flags, shmem);
+    const uint32_t eff = effective_flags(s.flat, flags);
+    int bpc = (flags & RT_F32) ? pathtrace_blocks_per_cu<float>(s.flat.feats, eff, shmem) : pathtrace_blocks_per_cu<double>(s.flat.feats, eff, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;
@@ -479,6 +500,15 @@ int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {
     if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
     HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
     HIP_OK(hipMemcpy(out, sc->s.d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+// BVH scenes: {advance passes, lanes advancing, traversal steps, lanes stepping} summed over waves; zeros for list scenes
+int rt_last_traversal_stats(rt_scene* sc, unsigned long long out[4]) {
+    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
+    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
+    unsigned long long h[16];
+    HIP_OK(hipMemcpy(h, sc->s.d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    out[0] = h[1]; out[1] = h[2]; out[2] = h[9]; out[3] = h[10];
     return 0;
 }
 // diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections; zeros otherwise

@@ -37,7 +37,8 @@ enum Feat : uint32_t {
     F_DIELECTRIC = 1u << 5, // Dielectric material
     F_PBR = 1u << 6,        // principled material (PBR) + PDF::BRDF
     F_ALL = 0x7F,
-    F_NEAR_FIRST = 1u << 7  // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
+    F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
+    F_PERSIST = 1u << 8     // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
 };
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count;
@@ -98,7 +99,10 @@ template <typename T> struct KParams {
     uint32_t* queue;               // zeroed before launch
     double* out;                   // n_local_tiles * tile_px * 3 (always f64: per-pixel sums)
     double* samples_out;           // optional: local_px * spp * 3
-    unsigned long long* stats;     // [0] non-finite samples, [1] bounce iterations, [2] lane-iterations active
+    unsigned long long* stats;     // [0] non-finite samples, [1] bounce iterations, [2] lane-iterations active, [9] traversal steps, [10] lanes stepping
+    // BVH scenes (persistent traversal): a traversal pass starts once trav_hi lanes are inside a BVH and runs until fewer
+    // than trav_lo are still walking
+    uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
 };
 
 } // namespace rt

@@ -408,36 +408,43 @@ DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_
     return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim);
 }
 
+// One object of the top-level list under HittableList::hit (hit.rs:59-71): offered [t_min, closest], a hit replaces the
+// running (closest, id).  ConstantMedium objects draw from the path's RNG (medium.rs:44).
+template <typename T, uint32_t FEATS>
+DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack) {
+    RayT<T> r = ray;
+    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+    if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
+        T t; uint32_t prim;
+        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+    } else {
+        // ConstantMedium::hit, medium.rs:27-61
+        T t1, t2; uint32_t p1, p2;
+        if (geom_hit<T, FEATS>(P, ob, r, -Lim<T>::max(), Lim<T>::max(), t1, p1, stack)) {
+            if (geom_hit<T, FEATS>(P, ob, r, t1 + T(0.0001), Lim<T>::max(), t2, p2, stack)) {
+                if (t1 < t_min) t1 = t_min;
+                if (t2 > closest) t2 = closest;
+                if (t1 < t2) {
+                    T len = length(ray.d);
+                    T distance_inside_boundary = (t2 - t1) * len;
+                    T hit_distance = cl(&P.media[ob.medium].neg_inv_density) * m_log(rng_u01(rng, T(0)));
+                    if (hit_distance < distance_inside_boundary) {
+                        closest = t1 + hit_distance / len;
+                        id.obj = oi; id.prim = PRIM_MEDIUM; any = true;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <typename T, uint32_t FEATS>
 DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack) {
     T closest = Lim<T>::inf();
     bool any = false;
     for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
         const DObject ob = ld_obj(P.objects + oi);
-        RayT<T> r = ray;
-        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
-        if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
-            T t; uint32_t prim;
-            if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
-        } else {
-            // ConstantMedium::hit, medium.rs:27-61
-            T t1, t2; uint32_t p1, p2;
-            if (geom_hit<T, FEATS>(P, ob, r, -Lim<T>::max(), Lim<T>::max(), t1, p1, stack)) {
-                if (geom_hit<T, FEATS>(P, ob, r, t1 + T(0.0001), Lim<T>::max(), t2, p2, stack)) {
-                    if (t1 < t_min) t1 = t_min;
-                    if (t2 > closest) t2 = closest;
-                    if (t1 < t2) {
-                        T len = length(ray.d);
-                        T distance_inside_boundary = (t2 - t1) * len;
-                        T hit_distance = cl(&P.media[ob.medium].neg_inv_density) * m_log(rng_u01(rng, T(0)));
-                        if (hit_distance < distance_inside_boundary) {
-                            closest = t1 + hit_distance / len;
-                            id.obj = oi; id.prim = PRIM_MEDIUM; any = true;
-                        }
-                    }
-                }
-            }
-        }
+        object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
     }
     t_hit = closest;
     return any;
@@ -822,8 +829,9 @@ DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out,
     }
 }
 
-// ------------------------------------------------------------------ the kernel
+// ------------------------------------------------------------------ wave-uniform work cursor + regeneration queue
 static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-wave regeneration queue (sized for f64), 5120 B
+static const uint32_t NONE_PX = 0xFFFFFFFFu;
 // RT_DIAG (diagnostic build only, never shipped): per-section wave-cycle shares via s_memtime, written to stats[3..8].
 #ifdef RT_DIAG
 #define DIAG_DECL unsigned long long dg_t = 0, dg_sum[6] = {0, 0, 0, 0, 0, 0};
@@ -834,38 +842,249 @@ static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-w
 #define DIAG_T0() do {} while (0)
 #define DIAG_ADD(k) do {} while (0)
 #endif
-template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 : 3))) pathtrace_kernel(const KParams<T> P) {
-    // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    unsigned char* regen = lds_raw + wave_in_block * REGEN_BYTES;
-    T* q_real = (T*)regen;                                         // [7][64]: o.x o.y o.z d.x d.y d.z time
-    uint32_t* q_u32 = (uint32_t*)(regen + 7u * 64u * sizeof(T));   // [6][64]: rng s0..s3, local pixel, sample
-    uint32_t* stack = (uint32_t*)(lds_raw + 4u * REGEN_BYTES) + wave_in_block * (P.stack_depth * 64u) + lane;
 
+// Everything here is wave-uniform (lives in SGPRs).  Work cursor: samples [cur_s, s_hi) of local pixel cur_px, then pixels
+// up to end_px (one dequeued chunk); cur_gp / cur_i / cur_j are the cursor pixel's global index and image coordinates,
+// recomputed once per pixel, not per sample.  Regeneration queue: entries [q_head, q_head + q_count) of this wave's LDS
+// queue hold camera paths that were generated 64 at a time with every lane busy; lanes whose path ended pop one instead
+// of running the camera code themselves at ~1/3 lane occupancy.
+struct WaveWork {
+    uint32_t cur_px, end_px, cur_s, s_lo, s_hi;
+    uint32_t cur_gp, cur_i, cur_j;
+    uint32_t q_head, q_count;
+    bool queue_done;
+};
+template <typename T> DEV void locate(const KParams<T>& P, WaveWork& w) {   // local pixel -> global output-order pixel (tile t = rank + q * world)
+    uint32_t q = w.cur_px / P.tile_px, kk = w.cur_px - q * P.tile_px;
+    w.cur_gp = (P.rank + q * P.world) * P.tile_px + kk;
+    uint32_t row = w.cur_gp / P.W;
+    w.cur_i = w.cur_gp - row * P.W;
+    w.cur_j = P.H - 1u - row;           // row 0 is j = H-1, main.rs:772
+}
+// Refill the queue: the next (up to) 64 samples of the cursor, all lanes generating (main.rs:813-820).  False when the
+// global work queue is exhausted and nothing was generated.
+template <typename T>
+DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32) {
     const uint32_t n_local_px = P.n_local_tiles * P.tile_px;
     const uint32_t n_px = P.W * P.H;
-    const uint32_t NONE = 0xFFFFFFFFu;
+    bool have = false;
+    uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
+    uint32_t n_gen = 0;
+    while (n_gen < 64u) {
+        if (w.cur_px == w.end_px) {
+            uint32_t c = 0;
+            if (lane == 0) c = atomicAdd(P.queue, 1u);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+            if (c >= P.n_chunks) { w.queue_done = true; break; }
+            if (c < P.n_coarse_px) {                      // a whole pixel
+                w.cur_px = c; w.end_px = c + 1u; w.s_lo = 0u; w.s_hi = P.spp;
+            } else {
+                const uint32_t c2 = c - P.n_coarse_px;
+                const uint32_t cp = c2 / P.chunks_per_px, sub = c2 - cp * P.chunks_per_px;
+                w.cur_px = P.n_coarse_px + cp * P.chunk_px;
+                w.end_px = w.cur_px + P.chunk_px; if (w.end_px > n_local_px) w.end_px = n_local_px;
+                w.s_lo = sub * P.chunk_spp;
+                w.s_hi = w.s_lo + P.chunk_spp; if (w.s_hi > P.spp) w.s_hi = P.spp;
+            }
+            w.cur_s = w.s_lo;
+            locate(P, w);
+        }
+        if (w.cur_gp >= n_px || w.s_lo >= w.s_hi) { w.cur_px++; w.cur_s = w.s_lo; if (w.cur_px != w.end_px) locate(P, w); continue; }   // padding pixel / empty range
+        uint32_t avail = w.s_hi - w.cur_s;
+        uint32_t room = 64u - n_gen;
+        uint32_t take = room < avail ? room : avail;
+        if (lane >= n_gen && lane < n_gen + take) { have = true; g_px = w.cur_px; g_s = w.cur_s + (lane - n_gen); g_gp = w.cur_gp; g_i = w.cur_i; g_j = w.cur_j; }
+        n_gen += take;
+        w.cur_s += take;
+        if (w.cur_s == w.s_hi) { w.cur_px++; w.cur_s = w.s_lo; if (w.cur_px != w.end_px) locate(P, w); }
+    }
+    if (n_gen == 0) return false;
+    if (have) {
+        Rng g = rng_for_path(P.seed, g_gp, g_s);
+        T random_u = rng_u01(g, T(0));
+        T random_v = rng_u01(g, T(0));
+        T u = (T(g_i) + random_u) / T(P.W - 1u);
+        T v = (T(g_j) + random_v) / T(P.H - 1u);
+        // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
+        T da, db;
+        for (;;) {
+            da = rng_range(g, T(-1.0), T(1.0));
+            db = rng_range(g, T(-1.0), T(1.0));
+            V3<T> pd = mk<T>(da, db, T(0));
+            if (dot(pd, pd) < T(1.0)) break;       // `p.length() < 1.0` (vec.rs:101): sqrt(x) < 1 <=> x < 1
+        }
+        V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
+        V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
+        T time = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
+        V3<T> go = ld3(P.cam.origin) + offset;
+        V3<T> gd = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
+        q_real[0u * 64u + lane] = go.x; q_real[1u * 64u + lane] = go.y; q_real[2u * 64u + lane] = go.z;
+        q_real[3u * 64u + lane] = gd.x; q_real[4u * 64u + lane] = gd.y; q_real[5u * 64u + lane] = gd.z;
+        q_real[6u * 64u + lane] = time;
+        q_u32[0u * 64u + lane] = g.s0; q_u32[1u * 64u + lane] = g.s1; q_u32[2u * 64u + lane] = g.s2; q_u32[3u * 64u + lane] = g.s3;
+        q_u32[4u * 64u + lane] = g_px; q_u32[5u * 64u + lane] = g_s;
+    }
+    w.q_head = 0; w.q_count = n_gen;
+    __builtin_amdgcn_wave_barrier();          // one wave: LDS writes above are ordered before the reads below
+    return true;
+}
+// Lanes with `dead` set take the next camera path from the wave's queue ("compaction by regeneration").  True for the
+// lanes that got one (ray, rng, new_px, path_s are then the new path's).
+template <typename T>
+DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32, bool dead,
+                        RayT<T>& ray, Rng& rng, uint32_t& new_px, uint32_t& path_s) {
+    bool got_new = false;
+    for (;;) {
+        unsigned long long want = __ballot(dead && !got_new);
+        if (want == 0) break;
+        if (w.q_count == 0) {
+            if (w.queue_done) break;
+            if (!refill_queue(P, w, lane, q_real, q_u32)) break;
+        }
+        uint32_t n_want = (uint32_t)__popcll(want);
+        uint32_t take = n_want < w.q_count ? n_want : w.q_count;
+        uint32_t rank = lane_rank(want);
+        if (dead && !got_new && rank < take) {
+            const uint32_t e = w.q_head + rank;
+            got_new = true;
+            ray.o = mk<T>(q_real[0u * 64u + e], q_real[1u * 64u + e], q_real[2u * 64u + e]);
+            ray.d = mk<T>(q_real[3u * 64u + e], q_real[4u * 64u + e], q_real[5u * 64u + e]);
+            ray.tm = q_real[6u * 64u + e];
+            rng.s0 = q_u32[0u * 64u + e]; rng.s1 = q_u32[1u * 64u + e]; rng.s2 = q_u32[2u * 64u + e]; rng.s3 = q_u32[3u * 64u + e];
+            new_px = q_u32[4u * 64u + e]; path_s = q_u32[5u * 64u + e];
+        }
+        w.q_head += take; w.q_count -= take;
+    }
+    return got_new;
+}
 
-    // wave-uniform work cursor: samples [cur_s, spp) of local pixel cur_px, then pixels up to end_px (one dequeued
-    // chunk).  cur_gp / cur_i / cur_j: the cursor pixel's global index and image coordinates, recomputed (wave-uniform,
-    // once per pixel, not per sample) whenever the cursor moves.
-    uint32_t cur_px = 0, end_px = 0, cur_s = 0, s_lo = 0, s_hi = 0;      // the chunk's sample range per pixel is [s_lo, s_hi)
-    uint32_t cur_gp = 0, cur_i = 0, cur_j = 0;
-    bool queue_done = false;
-    auto locate = [&]() {                 // local pixel -> global output-order pixel (tile t = rank + q * world)
-        uint32_t q = cur_px / P.tile_px, kk = cur_px - q * P.tile_px;
-        cur_gp = (P.rank + q * P.world) * P.tile_px + kk;
-        uint32_t row = cur_gp / P.W;
-        cur_i = cur_gp - row * P.W;
-        cur_j = P.H - 1u - row;           // row 0 is j = H-1, main.rs:772
-    };
-    // regeneration queue (wave-uniform): entries [q_head, q_head + q_count) of this wave's LDS queue hold camera paths
-    // that were generated 64 at a time with every lane busy; lanes whose path ended pop one instead of running the
-    // camera code themselves at ~1/3 lane occupancy.
-    uint32_t q_head = 0, q_count = 0;
+// ------------------------------------------------------------------ one level of ray_color after the hit: main.rs:50-116
+// In: the hit record.  In/out: ray (becomes the scattered ray), beta, rng, depth_left.  Out: done (the path ends here) and
+// e, the terminal radiance to be multiplied by beta.
+template <typename T, uint32_t FEATS>
+DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& beta, Rng& rng, uint32_t& depth_left, bool& done, V3<T>& e) {
+    const DMaterial<T> mt = ld_mat(P.materials + rec.mat);
+    if (mt.kind == M_LAMBERTIAN) {                                          // mat.rs:225-249, main.rs:92-98
+        V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+        Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::cosine_pdf, pdf.rs:81-85
+        V3<T> dir; T pdf_value;
+        if (P.n_lights == 0u) {                                             // stated deviation D2 (reference panics)
+            dir = onb_local(uvw, random_cosine_direction<T>(rng));
+            T cosine = dot(normalized(dir), uvw.w);
+            pdf_value = (cosine > T(0)) ? cosine / PI_T : T(0);
+        } else {
+            if (rng_bool(rng)) {                                            // pdf.rs:167-173
+                uint32_t li = rng_index(rng, P.n_lights);                   // hit.rs:94-96
+                dir = light_random<T, FEATS>(P, ld_light(P.lights + li), rec.p, rng);
+            } else {
+                dir = onb_local(uvw, random_cosine_direction<T>(rng));
+            }
+            T lsum = T(0);                                                  // hit.rs:90-92
+            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
+            T lpdf = lsum / T(P.n_lights);
+            T cosine = dot(normalized(dir), uvw.w);                         // pdf.rs:131-139
+            T cpdf = (cosine > T(0)) ? cosine / PI_T : T(0);
+            pdf_value = T(0.5) * lpdf + T(0.5) * cpdf;                      // pdf.rs:143-145
+        }
+        T sc = m_max(dot(rec.n, normalized(dir)), T(0)) / PI_T;             // scattering_pdf, mat.rs:246-249
+        beta = (beta * (attenuation * sc)) / pdf_value;                     // main.rs:97 (emitted is the literal zero here)
+        ray.o = rec.p; ray.d = dir;                                         // time unchanged
+    } else if (mt.kind == M_METAL) {                                        // mat.rs:280-293
+        V3<T> dn = ray.d + ((-dot(ray.d, rec.n)) * T(2.0) * rec.n);         // reflect, vec.rs:112-114
+        V3<T> reflected = normalized(dn);
+        V3<T> fz = random_in_unit_sphere<T>(rng);
+        V3<T> sd = reflected + mt.param * fz;
+        if (dot(sd, rec.n) > T(0)) { beta = ld3(mt.albedo) * beta; ray.o = rec.p; ray.d = sd; }   // main.rs:89-91
+        else done = true;                                                   // None -> emitted = 0, main.rs:108-110
+    } else if ((FEATS & F_DIELECTRIC) && mt.kind == M_DIELECTRIC) {         // mat.rs:343-374
+        T refraction_ratio = rec.front ? T(1.0) / mt.param : mt.param;
+        V3<T> unit_direction = normalized(ray.d);
+        T cos_theta = m_min(dot(T(-1.0) * unit_direction, rec.n), T(1.0));
+        T sin_theta = rsqrt_(T(1.0) - cos_theta * cos_theta);
+        bool cannot_refract = refraction_ratio * sin_theta > T(1.0);
+        T q = (T(1.0) - refraction_ratio) / (T(1.0) + refraction_ratio);    // reflectance, mat.rs:309-313
+        T r0 = q * q;
+        T m1 = T(1.0) - cos_theta, m2 = m1 * m1;
+        T refl = r0 + (T(1.0) - r0) * (m1 * (m2 * m2));
+        bool will_reflect = rng_u01(rng, T(0)) < refl;
+        V3<T> direction;
+        if (cannot_refract || will_reflect) {
+            direction = unit_direction + ((-dot(unit_direction, rec.n)) * T(2.0) * rec.n);
+        } else {                                                            // refract, vec.rs:116-121
+            T ct = m_min(dot(T(-1.0) * unit_direction, rec.n), T(1.0));
+            V3<T> r_out_perp = refraction_ratio * (unit_direction + ct * rec.n);
+            T l = length(r_out_perp);
+            V3<T> r_out_para = (T(-1.0) * rsqrt_(m_abs(T(1.0) - l * l))) * rec.n;
+            direction = r_out_perp + r_out_para;
+        }
+        ray.o = rec.p; ray.d = direction;                                   // attenuation (1,1,1): beta unchanged
+    } else if ((FEATS & F_PBR) && mt.kind == M_PBR) {                       // mat.rs:118-131 + main.rs:99-105 (Microfacet arm)
+        const DPbr<T> pm = ld_pbr(P.pbr + (uint32_t)mt.albedo[0]);
+        Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::brdf_pdf, pdf.rs:70-79
+        V3<T> dir; T pdf_value;
+        if (P.n_lights == 0u) {                                             // stated deviation D2
+            dir = brdf_pdf_generate(pm, uvw, ray.d, rng);
+            pdf_value = brdf_pdf_value(pm, uvw, ray.d, dir);
+        } else {
+            if (rng_bool(rng)) {
+                uint32_t li = rng_index(rng, P.n_lights);
+                dir = light_random<T, FEATS>(P, ld_light(P.lights + li), rec.p, rng);
+            } else {
+                dir = brdf_pdf_generate(pm, uvw, ray.d, rng);
+            }
+            T lsum = T(0);
+            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
+            pdf_value = T(0.5) * (lsum / T(P.n_lights)) + T(0.5) * brdf_pdf_value(pm, uvw, ray.d, dir);
+        }
+        V3<T> base = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+        V3<T> f = pbr_brdf(pm, base, ray.d, dir, rec.n);
+        beta = (beta * f) / pdf_value;                                      // main.rs:104
+        ray.o = rec.p; ray.d = dir;
+    } else if (mt.kind == M_DIFFUSE_LIGHT) {                                // mat.rs:395-401; no scatter -> main.rs:108-110
+        if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+        done = true;
+    } else if ((FEATS & F_MEDIUM) && (P.flags & 4u) && mt.kind == M_ISOTROPIC) {   // RT_ISOTROPIC_SCATTER (opt-in, non-reference):
+        V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);     // the old Isotropic::scatter, mat.rs:418-421
+        V3<T> sd = random_in_unit_sphere<T>(rng);
+        beta = attenuation * beta; ray.o = rec.p; ray.d = sd;
+    } else {                                                                // Isotropic: no scatter_mc_method (mat.rs:417-422) -> absorbs
+        done = true;
+    }
+    if (!done) {
+        depth_left--;
+        if (depth_left == 0) done = true;                                   // the child call returns 0 at main.rs:42-45
+        if ((P.flags & 2u) && beta.x == T(0) && beta.y == T(0) && beta.z == T(0)) done = true;   // RT_STOP_ON_ZERO (opt-in)
+    }
+}
 
+// A finished path hands in beta * e (kept even when e = 0, so that inf * 0 = NaN poisons a sample exactly when the
+// reference's arithmetic does).
+template <typename T>
+DEV void add_radiance(const KParams<T>& P, V3<T> L, double acc[3], uint32_t& n_nonfinite, uint32_t path_px, uint32_t path_s) {
+    double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
+    acc[0] += l0; acc[1] += l1; acc[2] += l2;
+    if (!(l0 - l0 == 0.0 && l1 - l1 == 0.0 && l2 - l2 == 0.0)) n_nonfinite++;
+    if (P.samples_out) {
+        double* so = P.samples_out + ((size_t)path_px * P.spp + path_s) * 3u;
+        so[0] = l0; so[1] = l1; so[2] = l2;
+    }
+}
+DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfinite, unsigned long long n_iters, unsigned long long n_active) {
+    if (!stats) return;
+    if (n_nonfinite) atomicAdd(&stats[0], (unsigned long long)n_nonfinite);
+    unsigned long long a = n_active;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], a); }
+}
+
+// ------------------------------------------------------------------ list scenes: lock-step bounce loop
+// Every iteration: dead lanes regenerate, then all 64 lanes run one level of ray_color together (closest hit over the
+// wave-uniform object list, hit record, material).  Used when the scene has no BVH: every lane's closest-hit search costs
+// the same, so lock-step wastes nothing.
+template <typename T, uint32_t FEATS>
+DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack) {
+    WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
     // per-lane path state
     bool alive = false;
     RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
@@ -873,7 +1092,7 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 :
     uint32_t depth_left = 0, path_px = 0, path_s = 0;
     Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     // per-lane accumulator for one local pixel
-    uint32_t acc_px = NONE;
+    uint32_t acc_px = NONE_PX;
     double acc[3] = {0.0, 0.0, 0.0};
     uint32_t n_nonfinite = 0;
     unsigned long long n_iters = 0, n_active = 0;
@@ -882,93 +1101,13 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 :
     for (;;) {
         DIAG_T0();
         // ---- lanes whose path has ended take the next camera path from the wave's queue
-        bool got_new = false;
         uint32_t new_px = 0;
-        for (;;) {
-            unsigned long long want = __ballot(!alive && !got_new);
-            if (want == 0) break;
-            if (q_count == 0) {
-                // -- refill the queue: the next (up to) 64 samples of the cursor, all lanes generating (main.rs:813-820)
-                if (queue_done) break;
-                bool have = false;
-                uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
-                uint32_t n_gen = 0;
-                while (n_gen < 64u) {
-                    if (cur_px == end_px) {
-                        uint32_t c = 0;
-                        if (lane == 0) c = atomicAdd(P.queue, 1u);
-                        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                        if (c >= P.n_chunks) { queue_done = true; break; }
-                        if (c < P.n_coarse_px) {                      // a whole pixel
-                            cur_px = c; end_px = c + 1u; s_lo = 0u; s_hi = P.spp;
-                        } else {
-                            const uint32_t c2 = c - P.n_coarse_px;
-                            const uint32_t cp = c2 / P.chunks_per_px, sub = c2 - cp * P.chunks_per_px;
-                            cur_px = P.n_coarse_px + cp * P.chunk_px;
-                            end_px = cur_px + P.chunk_px; if (end_px > n_local_px) end_px = n_local_px;
-                            s_lo = sub * P.chunk_spp;
-                            s_hi = s_lo + P.chunk_spp; if (s_hi > P.spp) s_hi = P.spp;
-                        }
-                        cur_s = s_lo;
-                        locate();
-                    }
-                    if (cur_gp >= n_px || s_lo >= s_hi) { cur_px++; cur_s = s_lo; if (cur_px != end_px) locate(); continue; }   // padding pixel / empty range
-                    uint32_t avail = s_hi - cur_s;
-                    uint32_t room = 64u - n_gen;
-                    uint32_t take = room < avail ? room : avail;
-                    if (lane >= n_gen && lane < n_gen + take) { have = true; g_px = cur_px; g_s = cur_s + (lane - n_gen); g_gp = cur_gp; g_i = cur_i; g_j = cur_j; }
-                    n_gen += take;
-                    cur_s += take;
-                    if (cur_s == s_hi) { cur_px++; cur_s = s_lo; if (cur_px != end_px) locate(); }
-                }
-                if (n_gen == 0) break;
-                if (have) {
-                    Rng g = rng_for_path(P.seed, g_gp, g_s);
-                    T random_u = rng_u01(g, T(0));
-                    T random_v = rng_u01(g, T(0));
-                    T u = (T(g_i) + random_u) / T(P.W - 1u);
-                    T v = (T(g_j) + random_v) / T(P.H - 1u);
-                    // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
-                    T da, db;
-                    for (;;) {
-                        da = rng_range(g, T(-1.0), T(1.0));
-                        db = rng_range(g, T(-1.0), T(1.0));
-                        V3<T> pd = mk<T>(da, db, T(0));
-                        if (dot(pd, pd) < T(1.0)) break;       // `p.length() < 1.0` (vec.rs:101): sqrt(x) < 1 <=> x < 1
-                    }
-                    V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
-                    V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
-                    T time = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
-                    V3<T> go = ld3(P.cam.origin) + offset;
-                    V3<T> gd = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
-                    q_real[0u * 64u + lane] = go.x; q_real[1u * 64u + lane] = go.y; q_real[2u * 64u + lane] = go.z;
-                    q_real[3u * 64u + lane] = gd.x; q_real[4u * 64u + lane] = gd.y; q_real[5u * 64u + lane] = gd.z;
-                    q_real[6u * 64u + lane] = time;
-                    q_u32[0u * 64u + lane] = g.s0; q_u32[1u * 64u + lane] = g.s1; q_u32[2u * 64u + lane] = g.s2; q_u32[3u * 64u + lane] = g.s3;
-                    q_u32[4u * 64u + lane] = g_px; q_u32[5u * 64u + lane] = g_s;
-                }
-                q_head = 0; q_count = n_gen;
-                __builtin_amdgcn_wave_barrier();          // one wave: LDS writes above are ordered before the reads below
-            }
-            uint32_t n_want = (uint32_t)__popcll(want);
-            uint32_t take = n_want < q_count ? n_want : q_count;
-            uint32_t rank = lane_rank(want);
-            if (!alive && !got_new && rank < take) {
-                const uint32_t e = q_head + rank;
-                got_new = true;
-                ray.o = mk<T>(q_real[0u * 64u + e], q_real[1u * 64u + e], q_real[2u * 64u + e]);
-                ray.d = mk<T>(q_real[3u * 64u + e], q_real[4u * 64u + e], q_real[5u * 64u + e]);
-                ray.tm = q_real[6u * 64u + e];
-                rng.s0 = q_u32[0u * 64u + e]; rng.s1 = q_u32[1u * 64u + e]; rng.s2 = q_u32[2u * 64u + e]; rng.s3 = q_u32[3u * 64u + e];
-                new_px = q_u32[4u * 64u + e]; path_s = q_u32[5u * 64u + e];
-            }
-            q_head += take; q_count -= take;
-        }
+        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
         if (__ballot(alive || got_new) == 0) break;     // queue empty and every path finished
         DIAG_ADD(0);
 
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(got_new && acc_px != NONE && acc_px != new_px, acc_px, acc, P.out, lane);
+        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane);
 
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
@@ -995,131 +1134,238 @@ __global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 :
                 if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
                 } else {
-                    // material of the hit decides whether (u,v) are needed at all
                     Rec<T> rec;
                     finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
                     DIAG_ADD(3);
-                    const DMaterial<T> mt = ld_mat(P.materials + rec.mat);
-                    if (mt.kind == M_LAMBERTIAN) {                                          // mat.rs:225-249, main.rs:92-98
-                        V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
-                        Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::cosine_pdf, pdf.rs:81-85
-                        V3<T> dir; T pdf_value;
-                        if (P.n_lights == 0u) {                                             // stated deviation D2 (reference panics)
-                            dir = onb_local(uvw, random_cosine_direction<T>(rng));
-                            T cosine = dot(normalized(dir), uvw.w);
-                            pdf_value = (cosine > T(0)) ? cosine / PI_T : T(0);
-                        } else {
-                            if (rng_bool(rng)) {                                            // pdf.rs:167-173
-                                uint32_t li = rng_index(rng, P.n_lights);                   // hit.rs:94-96
-                                dir = light_random<T, FEATS>(P, ld_light(P.lights + li), rec.p, rng);
-                            } else {
-                                dir = onb_local(uvw, random_cosine_direction<T>(rng));
-                            }
-                            T lsum = T(0);                                                  // hit.rs:90-92
-                            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
-                            T lpdf = lsum / T(P.n_lights);
-                            T cosine = dot(normalized(dir), uvw.w);                         // pdf.rs:131-139
-                            T cpdf = (cosine > T(0)) ? cosine / PI_T : T(0);
-                            pdf_value = T(0.5) * lpdf + T(0.5) * cpdf;                      // pdf.rs:143-145
-                        }
-                        T sc = m_max(dot(rec.n, normalized(dir)), T(0)) / PI_T;             // scattering_pdf, mat.rs:246-249
-                        beta = (beta * (attenuation * sc)) / pdf_value;                     // main.rs:97 (emitted is the literal zero here)
-                        ray.o = rec.p; ray.d = dir;                                         // time unchanged
-                    } else if (mt.kind == M_METAL) {                                        // mat.rs:280-293
-                        V3<T> dn = ray.d + ((-dot(ray.d, rec.n)) * T(2.0) * rec.n);         // reflect, vec.rs:112-114
-                        V3<T> reflected = normalized(dn);
-                        V3<T> fz = random_in_unit_sphere<T>(rng);
-                        V3<T> sd = reflected + mt.param * fz;
-                        if (dot(sd, rec.n) > T(0)) { beta = ld3(mt.albedo) * beta; ray.o = rec.p; ray.d = sd; }   // main.rs:89-91
-                        else done = true;                                                   // None -> emitted = 0, main.rs:108-110
-                    } else if ((FEATS & F_DIELECTRIC) && mt.kind == M_DIELECTRIC) {         // mat.rs:343-374
-                        T refraction_ratio = rec.front ? T(1.0) / mt.param : mt.param;
-                        V3<T> unit_direction = normalized(ray.d);
-                        T cos_theta = m_min(dot(T(-1.0) * unit_direction, rec.n), T(1.0));
-                        T sin_theta = rsqrt_(T(1.0) - cos_theta * cos_theta);
-                        bool cannot_refract = refraction_ratio * sin_theta > T(1.0);
-                        T q = (T(1.0) - refraction_ratio) / (T(1.0) + refraction_ratio);    // reflectance, mat.rs:309-313
-                        T r0 = q * q;
-                        T m1 = T(1.0) - cos_theta, m2 = m1 * m1;
-                        T refl = r0 + (T(1.0) - r0) * (m1 * (m2 * m2));
-                        bool will_reflect = rng_u01(rng, T(0)) < refl;
-                        V3<T> direction;
-                        if (cannot_refract || will_reflect) {
-                            direction = unit_direction + ((-dot(unit_direction, rec.n)) * T(2.0) * rec.n);
-                        } else {                                                            // refract, vec.rs:116-121
-                            T ct = m_min(dot(T(-1.0) * unit_direction, rec.n), T(1.0));
-                            V3<T> r_out_perp = refraction_ratio * (unit_direction + ct * rec.n);
-                            T l = length(r_out_perp);
-                            V3<T> r_out_para = (T(-1.0) * rsqrt_(m_abs(T(1.0) - l * l))) * rec.n;
-                            direction = r_out_perp + r_out_para;
-                        }
-                        ray.o = rec.p; ray.d = direction;                                   // attenuation (1,1,1): beta unchanged
-                    } else if ((FEATS & F_PBR) && mt.kind == M_PBR) {                       // mat.rs:118-131 + main.rs:99-105 (Microfacet arm)
-                        const DPbr<T> pm = ld_pbr(P.pbr + (uint32_t)mt.albedo[0]);
-                        Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::brdf_pdf, pdf.rs:70-79
-                        V3<T> dir; T pdf_value;
-                        if (P.n_lights == 0u) {                                             // stated deviation D2
-                            dir = brdf_pdf_generate(pm, uvw, ray.d, rng);
-                            pdf_value = brdf_pdf_value(pm, uvw, ray.d, dir);
-                        } else {
-                            if (rng_bool(rng)) {
-                                uint32_t li = rng_index(rng, P.n_lights);
-                                dir = light_random<T, FEATS>(P, ld_light(P.lights + li), rec.p, rng);
-                            } else {
-                                dir = brdf_pdf_generate(pm, uvw, ray.d, rng);
-                            }
-                            T lsum = T(0);
-                            for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
-                            pdf_value = T(0.5) * (lsum / T(P.n_lights)) + T(0.5) * brdf_pdf_value(pm, uvw, ray.d, dir);
-                        }
-                        V3<T> base = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
-                        V3<T> f = pbr_brdf(pm, base, ray.d, dir, rec.n);
-                        beta = (beta * f) / pdf_value;                                      // main.rs:104
-                        ray.o = rec.p; ray.d = dir;
-                    } else if (mt.kind == M_DIFFUSE_LIGHT) {                                // mat.rs:395-401; no scatter -> main.rs:108-110
-                        if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
-                        done = true;
-                    } else if ((FEATS & F_MEDIUM) && (P.flags & 4u) && mt.kind == M_ISOTROPIC) {   // RT_ISOTROPIC_SCATTER (opt-in, non-reference):
-                        V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);     // the old Isotropic::scatter, mat.rs:418-421
-                        V3<T> sd = random_in_unit_sphere<T>(rng);
-                        beta = attenuation * beta; ray.o = rec.p; ray.d = sd;
-                    } else {                                                                // Isotropic: no scatter_mc_method (mat.rs:417-422) -> absorbs
-                        done = true;
-                    }
-                    if (!done) {
-                        depth_left--;
-                        if (depth_left == 0) done = true;                                   // the child call returns 0 at main.rs:42-45
-                        if ((P.flags & 2u) && beta.x == T(0) && beta.y == T(0) && beta.z == T(0)) done = true;   // RT_STOP_ON_ZERO (opt-in)
-                    }
+                    shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
                 }
             }
             DIAG_ADD(4);
             if (done) {
-                V3<T> L = beta * e;
-                double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
-                acc[0] += l0; acc[1] += l1; acc[2] += l2;
-                if (!(l0 - l0 == 0.0 && l1 - l1 == 0.0 && l2 - l2 == 0.0)) n_nonfinite++;
-                if (P.samples_out) {
-                    double* so = P.samples_out + ((size_t)path_px * P.spp + path_s) * 3u;
-                    so[0] = l0; so[1] = l1; so[2] = l2;
-                }
+                add_radiance(P, beta * e, acc, n_nonfinite, path_px, path_s);
                 alive = false;
             }
             DIAG_ADD(5);
         }
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(acc_px != NONE, acc_px, acc, P.out, lane);
+    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane);
+    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active);
+#ifdef RT_DIAG
+    if (P.stats && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.stats[3 + k], dg_sum[k]);
+#endif
+}
+
+// ------------------------------------------------------------------ BVH scenes: resumable closest-hit search, persistent traversal
+// With a BVH in the scene the cost of `world.hit` differs wildly between lanes (a ray that misses the root box is done
+// after one node, its neighbour walks a hundred), and in lock-step every lane waits for the slowest one: *measured* VALU
+// lane utilisation 16 % (teapot room) to 27 % (final scene), ~90 % of the time spent in traversal.  Here a lane's
+// closest-hit search is a small state machine instead:
+//   PH_NEW   needs a camera path            PH_OBJ   walking the top-level list, at object my_oi
+//   PH_BVH   inside the BVH of object my_oi  PH_SHADE list finished: hit record + material next
+// and the wave alternates between two kinds of passes.  An *advance* pass is one lock-step iteration for the lanes that
+// are not inside a BVH (regenerate; walk the list up to the next BVH object or to its end; shade).  A *traversal* pass
+// steps the BVH lanes, one node per step, and stops as soon as fewer than `trav_lo` of them are still walking: the
+// finished ones go through an advance pass (which also brings fresh rays to the BVH) while the stragglers simply keep
+// their node/stack and resume in the next traversal pass together with the newcomers.  Traversal therefore runs with
+// between trav_lo and 64 lanes busy instead of "whoever is slowest".  Per lane the order of operations (objects in push
+// order, bbox / left / right, t_max shrinking, RNG draws) is exactly the lock-step one, so samples are bit-identical.
+enum : uint32_t { PH_NEW = 0u, PH_OBJ = 1u, PH_BVH = 2u, PH_SHADE = 3u };
+
+template <typename T, uint32_t FEATS>
+DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack) {
+    WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
+    const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;
+    // per-lane path state
+    uint32_t phase = PH_NEW;
+    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
+    V3<T> beta = mk<T>(T(0), T(0), T(0));
+    uint32_t depth_left = 0, path_px = 0, path_s = 0;
+    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    // closest-hit search of the current level (HittableList::hit, hit.rs:59-71)
+    uint32_t my_oi = 0;
+    T closest = Lim<T>::inf();
+    HitId id; id.obj = 0; id.prim = 0;
+    bool any_hit = false;
+    // traversal state while phase == PH_BVH (the node stack is the lane's LDS column)
+    const uint32_t BVH_DONE = 0xFFFFFFFFu;
+    uint32_t tv_node = 0, tv_sp = 0, tv_prim = 0, tv_best = 0, tv_leaf_a = 0, tv_leaf_b = 0, tv_leaf_node = 0;
+    T tv_closest = T(0);
+    bool tv_any = false, tv_have_leaf = false;
+    // per-lane accumulator for one local pixel
+    uint32_t acc_px = NONE_PX;
+    double acc[3] = {0.0, 0.0, 0.0};
+    uint32_t n_nonfinite = 0;
+    unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0;
+    DIAG_DECL
+    DIAG_T0();
+
+    for (;;) {
+        const uint32_t n_bvh = (uint32_t)__popcll(__ballot(phase == PH_BVH));
+        const bool work_left = !(w.queue_done && w.q_count == 0u);
+        const uint32_t n_adv = (uint32_t)__popcll(__ballot(phase == PH_OBJ || phase == PH_SHADE || (phase == PH_NEW && work_left)));
+        if (n_bvh == 0u && n_adv == 0u) break;
+
+        if (n_bvh >= P.trav_hi || n_adv == 0u) {
+            // ================= traversal pass
+            // object-space ray of every traversing lane: recomputed on entry (the wrapper chain is short and wave-uniform
+            // per object) rather than kept alive through the advance passes
+            RayT<T> r = ray;
+            for (uint32_t oi = 0; oi < P.n_objects; oi++) {
+                const bool here = phase == PH_BVH && my_oi == oi;
+                if (__ballot(here) == 0) continue;
+                const DObject ob = ld_obj(P.objects + oi);
+                if (here) for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+            }
+            const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);      // AABB::hit's 1/d (aabb.rs:21), same value at every node
+            const T t_min = TMin<T>::v();
+            uint32_t stop_below = n_bvh * 3u / 4u;                  // entered below trav_hi (nothing else to do): until a quarter has finished
+            if (stop_below > P.trav_lo) stop_below = P.trav_lo;
+            if (stop_below < 1u) stop_below = 1u;
+            for (;;) {
+                const bool act = phase == PH_BVH;
+                const uint32_t n = (uint32_t)__popcll(__ballot(act));
+                if (n < stop_below) break;
+                // Two kinds of step, chosen by vote so that each runs with many lanes: a box step (lanes that hold a node:
+                // bbox test, descend / pop; a lane that reaches a leaf keeps it pending and waits) and a leaf step (lanes
+                // with a pending leaf: primitive tests).  Per lane the order bbox, left, right and the shrinking t_max are
+                // those of BVH::hit (bvh.rs:77-91) — a lane never walks on before its pending leaf has been tested.
+                const bool want_leaf = act && tv_have_leaf;
+                const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
+                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
+                const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box));
+                n_steps++;
+                if (n_box != 0u && n_leaf * 64u < P.trav_leaf * n) {
+                    if (want_box) {
+                        n_step_lanes++;
+                        const DBvhNode<T> nd = ld_node(P.bvh + tv_node);
+                        bool inside = true;
+                        {
+                            T t_in = t_min, t_o = tv_closest;
+#pragma unroll
+                            for (int a = 0; a < 3; a++) {
+                                T inv_d = a == 0 ? inv.x : (a == 1 ? inv.y : inv.z);
+                                T org = a == 0 ? r.o.x : (a == 1 ? r.o.y : r.o.z);
+                                T t0 = (nd.mn[a] - org) * inv_d;
+                                T t1 = (nd.mx[a] - org) * inv_d;
+                                if (inv_d < T(0)) { T tmp = t0; t0 = t1; t1 = tmp; }
+                                t_in = m_max(t_in, t0);
+                                t_o = m_min(t_o, t1);
+                                if (t_o <= t_in) inside = false;    // aabb.rs:31-33 returns here; later axes cannot un-fail it
+                            }
+                        }
+                        if (inside && !(nd.a & BVH_LEAF)) {
+                            const bool right_first = near_first && get(r.d, nd.a) < T(0);
+                            stack[tv_sp * 64u] = right_first ? tv_node + 1u : nd.b;      // the other child waits (reference order: right waits)
+                            tv_sp++;
+                            tv_node = right_first ? nd.b : tv_node + 1u;
+                        } else {
+                            if (inside) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = tv_node; }
+                            // this node is finished (culled, or a leaf now pending): the next one comes off the stack
+                            if (tv_sp == 0u) tv_node = BVH_DONE;
+                            else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
+                        }
+                    }
+                } else if (n_leaf != 0u) {
+                    if (want_leaf) {
+                        n_step_lanes++;
+                        T t; uint32_t prim;
+                        if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, r, t_min, tv_closest, t, prim) &&
+                            bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
+                        tv_have_leaf = false;
+                    }
+                }
+                if (act && !tv_have_leaf && tv_node == BVH_DONE) {
+                    // ---- this BVH is done: its result joins the list search (hit.rs:62-69), the lane moves to the next object
+                    if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
+                    my_oi++;
+                    phase = PH_OBJ;
+                }
+            }
+            DIAG_ADD(0);
+            continue;
+        }
+
+        // ================= advance pass
+        n_iters++;
+        if (phase == PH_OBJ || phase == PH_SHADE) n_active++;
+        // ---- lanes whose list search is complete: the rest of the level (main.rs:50-118), then the child level starts
+        if (phase == PH_OBJ && my_oi >= P.n_objects) phase = PH_SHADE;
+        if (phase == PH_SHADE) {
+            bool done = false;
+            V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
+            if (!any_hit) {
+                e = ld3(P.background); done = true;                                         // main.rs:118
+            } else {
+                Rec<T> rec;
+                finalize_hit<T, FEATS>(P, ray, closest, id, true, rec);
+                shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
+            }
+            if (done) {
+                add_radiance(P, beta * e, acc, n_nonfinite, path_px, path_s);
+                phase = PH_NEW;
+            } else {
+                phase = PH_OBJ; my_oi = 0; closest = Lim<T>::inf(); any_hit = false;
+            }
+        }
+        // ---- lanes whose path has ended take the next camera path from the wave's queue
+        uint32_t new_px = 0;
+        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
+        // ---- lanes moving on to another pixel hand in their partial sum
+        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane);
+        if (got_new) {
+            if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
+            path_px = new_px;
+            beta = mk<T>(T(1.0), T(1.0), T(1.0));
+            depth_left = P.max_depth;
+            phase = PH_OBJ; my_oi = 0; closest = Lim<T>::inf(); any_hit = false;
+            if (depth_left == 0u) {                     // main.rs:42-45: the sample is beta * 0
+                add_radiance(P, beta * mk<T>(T(0), T(0), T(0)), acc, n_nonfinite, path_px, path_s);
+                phase = PH_NEW;
+            }
+        }
+        // ---- world.hit (main.rs:48), resumable: objects in push order from my_oi up to the next BVH object or the end
+        for (uint32_t oi = 0; oi < P.n_objects; oi++) {
+            const bool here = phase == PH_OBJ && my_oi == oi;
+            if (__ballot(here) == 0) continue;
+            const DObject ob = ld_obj(P.objects + oi);
+            if (here) {
+                if (ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0)) {
+                    phase = PH_BVH; tv_node = ob.geom_first; tv_sp = 0; tv_closest = closest; tv_any = false; tv_best = 0; tv_have_leaf = false;
+                } else {
+                    object_hit<T, FEATS>(P, oi, ob, ray, TMin<T>::v(), rng, closest, id, any_hit, stack);
+                    my_oi = oi + 1u;
+                }
+            }
+        }
+        DIAG_ADD(1);
+    }
+    // ---- the queue is empty: hand in what is left
+    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane);
+    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active);
     if (P.stats) {
-        if (n_nonfinite) atomicAdd(&P.stats[0], (unsigned long long)n_nonfinite);
-        unsigned long long a = n_active;
+        unsigned long long a = n_step_lanes;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-        if (lane == 0) { atomicAdd(&P.stats[1], n_iters); atomicAdd(&P.stats[2], a); }
+        if (lane == 0) { atomicAdd(&P.stats[9], n_steps); atomicAdd(&P.stats[10], a); }
 #ifdef RT_DIAG
         if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.stats[3 + k], dg_sum[k]);
 #endif
     }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <typename T, uint32_t FEATS>
+__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 : 3))) pathtrace_kernel(const KParams<T> P) {
+    // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    unsigned char* regen = lds_raw + wave_in_block * REGEN_BYTES;
+    T* q_real = (T*)regen;                                         // [7][64]: o.x o.y o.z d.x d.y d.z time
+    uint32_t* q_u32 = (uint32_t*)(regen + 7u * 64u * sizeof(T));   // [6][64]: rng s0..s3, local pixel, sample
+    uint32_t* stack = (uint32_t*)(lds_raw + 4u * REGEN_BYTES) + wave_in_block * (P.stack_depth * 64u) + lane;
+    if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack);
+    else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack);
 }
 
 // ------------------------------------------------------------------ launch
@@ -1143,18 +1389,22 @@ static const uint32_t FEATS_LEAN = 0u;
 static const uint32_t FEATS_MESH = F_BVH | F_TRIS;
 static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
 
-template <typename T, typename F> static auto dispatch(uint32_t scene_feats, bool near_first, F&& f) {
-    const bool nf = near_first && (scene_feats & F_BVH);
+template <typename T, typename F> static auto dispatch(uint32_t scene_feats, uint32_t flags, F&& f) {
+    const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
+    const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
     if ((scene_feats & ~FEATS_LEAN) == 0u) return f(std::integral_constant<uint32_t, FEATS_LEAN>());
-    if ((scene_feats & ~FEATS_MESH) == 0u) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
+    if ((scene_feats & ~FEATS_MESH) == 0u) {
+        if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
+        return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
+    }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
     return nf ? f(std::integral_constant<uint32_t, F_ALL | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, F_ALL>());
 }
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
-    return dispatch<T>(scene_feats, (P.flags & 8u) != 0u, [&](auto feats) { return launch_one<T, decltype(feats)::value>(P, n_blocks, shmem, stream); });
+    return dispatch<T>(scene_feats, P.flags, [&](auto feats) { return launch_one<T, decltype(feats)::value>(P, n_blocks, shmem, stream); });
 }
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem) {
-    return dispatch<T>(scene_feats, (flags & 8u) != 0u, [&](auto feats) { return occupancy_one<T, decltype(feats)::value>(shmem); });
+    return dispatch<T>(scene_feats, flags, [&](auto feats) { return occupancy_one<T, decltype(feats)::value>(shmem); });
 }
 
 template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);

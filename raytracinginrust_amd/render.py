@@ -13,6 +13,7 @@ from . import _lib
 from .api import CameraParams, SceneBuilder
 
 RT_F64, RT_F32, RT_STOP_ON_ZERO, RT_ISOTROPIC_SCATTER, RT_NEAR_FIRST_BVH = 0, 1, 2, 4, 8
+RT_PERSISTENT_BVH, RT_LOCKSTEP_BVH = 16, 32
 FLATTEN_COUNT_NAMES = ("objects", "ops", "rects", "spheres", "moving_spheres", "triangles", "bvh_nodes",
                        "materials", "textures", "lights", "media", "perlins")
 
@@ -78,6 +79,15 @@ def render_tiles_device(b: SceneBuilder, cam: CameraParams, background, W: int, 
                                  C.c_void_p(d_out_ptr), d_out_bytes, C.c_void_p(stream))
     if rc != 0:
         raise RenderError(_err(be))
+
+
+def last_traversal_stats(b: SceneBuilder) -> dict:
+    """BVH scenes: advance passes / traversal steps of the last launch and the lanes busy in each (summed over wavefronts)."""
+    be = _lib.load()
+    out = (C.c_ulonglong * 4)()
+    if be.lib.rt_last_traversal_stats(b.h, out) != 0:
+        raise RenderError(_err(be))
+    return {"advance_passes": out[0], "advance_lanes": out[1], "traversal_steps": out[2], "traversal_lanes": out[3]}
 
 
 def last_kernel_ms(b: SceneBuilder) -> float:

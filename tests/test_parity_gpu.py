@@ -277,6 +277,83 @@ def test_prepare_does_not_change_the_render(pbe):
         R.prepare(SceneBuilder(pbe))                     # no world set
 
 
+def _mesh_room(be, seed):
+    """A lit room (rect list) with two triangle-mesh BVHs (one inside Translate(Rotate(..))) and a loose triangle: only
+    list + BVH + triangle features, i.e. the mesh kernel."""
+    rs = np.random.RandomState(seed)
+    b = SceneBuilder(be)
+    white = b.Lambertian(b.ConstantTexture((0.73, 0.73, 0.73)))
+    red = b.Lambertian(b.ConstantTexture((0.65, 0.05, 0.05)))
+    steel = b.Metal((0.8, 0.85, 0.88), 0.1)
+    light = b.DiffuseLight(b.ConstantTexture((12.0, 12.0, 12.0)))
+    world = b.HittableList()
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, 150.0, 400.0, 150.0, 400.0, 554.0, light))
+    world.push(lamp)
+    world.push(b.AARect(Plane.XZ, 0.0, 555.0, 0.0, 555.0, 0.0, white))
+    world.push(b.AARect(Plane.XY, 0.0, 555.0, 0.0, 555.0, 555.0, white))
+    world.push(b.AARect(Plane.YZ, 0.0, 555.0, 0.0, 555.0, 555.0, red))
+
+    def blob(center, radius, n, mat):
+        tris = []
+        for _ in range(n):
+            p0 = center + rs.uniform(-radius, radius, 3)
+            tris.append(b.Triangle([tuple(p0), tuple(p0 + rs.uniform(-25, 25, 3)), tuple(p0 + rs.uniform(-25, 25, 3))], mat))
+        return b.BVH(tris, 0.0, 1.0)
+
+    world.push(blob(np.array([200.0, 120.0, 250.0]), 70.0, int(rs.randint(40, 160)), white))
+    world.push(b.Triangle([(20.0, 20.0, 300.0), (120.0, 30.0, 280.0), (60.0, 200.0, 350.0)], steel))
+    world.push(b.Translate(b.Rotate(Axis.Y, blob(np.array([0.0, 0.0, 0.0]), 60.0, int(rs.randint(30, 120)), steel), float(rs.uniform(-40, 40))),
+                           (380.0, 200.0, 300.0)))
+    b.set_scene(world, [lamp])
+    cam = Camera((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return b, cam, (0.02, 0.02, 0.03)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+@pytest.mark.parametrize("extra", [0, R.RT_NEAR_FIRST_BVH])
+def test_persistent_traversal_is_scheduling_only(pbe, obe, orc_mod, seed, extra):
+    """RT_PERSISTENT_BVH / RT_LOCKSTEP_BVH change which lanes run when, never what a path computes: every sample is
+    bit-identical between the two loop shapes, and both match the oracle."""
+    b, cam, bg = _mesh_room(pbe, seed)
+    W, H, spp, depth = 40, 40, 8, 16
+    _, lock = R.render(b, cam, bg, W, H, spp, depth, seed=5 + seed, flags=R.RT_LOCKSTEP_BVH | extra, want_samples=True)
+    assert R.last_traversal_stats(b)["traversal_steps"] == 0
+    _, pers = R.render(b, cam, bg, W, H, spp, depth, seed=5 + seed, flags=R.RT_PERSISTENT_BVH | extra, want_samples=True)
+    tv = R.last_traversal_stats(b)
+    assert tv["traversal_steps"] > 0 and 0 < tv["traversal_lanes"] <= 64 * tv["traversal_steps"]
+    assert np.array_equal(lock.view(np.uint64), pers.view(np.uint64))
+    _, auto = R.render(b, cam, bg, W, H, spp, depth, seed=5 + seed, flags=extra, want_samples=True)
+    assert R.last_traversal_stats(b)["traversal_steps"] > 0          # a mesh BVH beside a list: persistent by default
+    assert np.array_equal(auto.view(np.uint64), pers.view(np.uint64))
+    if extra == 0:
+        ob, ocam, obg = _mesh_room(obe, seed)
+        _, ref = orc_mod.render(ob, ocam, obg, W, H, spp, depth, seed=5 + seed, want_samples=True)
+        assert np.array_equal(np.isnan(pers), np.isnan(ref))
+        fin = np.isfinite(ref)
+        d = np.abs(np.where(fin, pers, 0.0) - np.where(fin, ref, 0.0))
+        assert (d > 1e-9 * (1.0 + np.abs(np.where(fin, ref, 0.0)))).any(axis=-1).sum() <= 1
+
+
+def test_persistent_traversal_on_the_teapot_room(pbe):
+    b, cam, bg = scenes.cornell_test(pbe, scenes.asset_path("teapot.obj"))
+    W, H, spp, depth = 64, 64, 4, 50
+    _, lock = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
+    _, pers = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    assert R.last_traversal_stats(b)["traversal_steps"] > 0
+    assert np.array_equal(lock.view(np.uint64), pers.view(np.uint64))
+    # a BVH that is the whole world stays on the lock-step loop unless asked otherwise
+    mesh_only = SceneBuilder(pbe)
+    lam = mesh_only.Lambertian(mesh_only.ConstantTexture((0.5, 0.5, 0.5)))
+    tris = [mesh_only.Triangle([(float(i), 0.0, 0.0), (float(i) + 1.0, 0.0, 0.0), (float(i), 1.0, 0.0)], lam) for i in range(8)]
+    mesh_only.set_scene(mesh_only.BVH(tris, 0.0, 1.0), [])
+    cam2 = Camera((4.0, 0.5, -10.0), (4.0, 0.5, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    _, a = R.render(mesh_only, cam2, (0.5, 0.7, 1.0), 16, 16, 4, 5, want_samples=True)
+    assert R.last_traversal_stats(mesh_only)["traversal_steps"] == 0
+    _, c = R.render(mesh_only, cam2, (0.5, 0.7, 1.0), 16, 16, 4, 5, flags=R.RT_PERSISTENT_BVH, want_samples=True)
+    assert R.last_traversal_stats(mesh_only)["traversal_steps"] > 0
+    assert np.array_equal(a.view(np.uint64), c.view(np.uint64))
+
+
 def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
     b, cam, bg = _cornell(pbe)
     a = R.render(b, cam, bg, 64, 64, 32, 50)

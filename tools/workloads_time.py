@@ -7,7 +7,7 @@ from raytracinginrust_amd import _lib, render as R, scenes, workloads
 be = _lib.load()
 im = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB'); earth = (im.tobytes(), *im.size)
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-for key in ('C1', 'C2', 'C3', 'C4'):
+for key in os.environ.get('RT_WORKLOADS', 'C1,C2,C3,C4').split(','):
     w = workloads.WORKLOADS[key]
     b, cam, bg = workloads.build(w, be, earth)
     s = min(spp, w.spp)
@@ -15,4 +15,6 @@ for key in ('C1', 'C2', 'C3', 'C4'):
     for _ in range(2):
         out = R.render(b, cam, bg, w.W, w.H, s, w.max_depth, flags=flags)
     ms = R.last_kernel_ms(b); st = R.last_stats(b)
-    print(f'{key} {w.scene} {w.W}x{w.H} at {s} spp: {ms:9.2f} ms  {w.W*w.H*s/ms/1e3:8.1f} Msamples/s  lane util {st["live_lane_iterations"]/(64*st["wave_iterations"]):.3f}  -> full config ({w.spp} spp) ~ {ms*w.spp/s/1e3:.2f} s')
+    tv = R.last_traversal_stats(b)
+    trav = f"  adv {tv['advance_lanes']/max(1,64*tv['advance_passes']):.2f} x {tv['advance_passes']/1e6:.2f}M  trav {tv['traversal_lanes']/max(1,64*tv['traversal_steps']):.2f} x {tv['traversal_steps']/1e6:.1f}M" if tv['traversal_steps'] else ''
+    print(f'{key} {w.scene} {w.W}x{w.H} at {s} spp: {ms:9.2f} ms  {w.W*w.H*s/ms/1e3:8.1f} Msamples/s  lane util {st["live_lane_iterations"]/(64*st["wave_iterations"]):.3f}  -> full config ({w.spp} spp) ~ {ms*w.spp/s/1e3:.2f} s{trav}')
