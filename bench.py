@@ -130,6 +130,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     stats = R.last_stats(b)
+    n_flush = R.last_flush_count(b)
     el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -155,6 +156,8 @@ def main():
                     "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": bps * local_samples, "kernel": f"rt::pathtrace_kernel<{'float' if args.f32 else 'double'}, FEATS> (FEATS = 0 for the Cornell box; the leanest instantiation covering the scene)",
                     "kernel_ms": k_ms, "bytes_per_sample": bps,
+                    "framebuffer_atomics_per_launch": 3 * n_flush,       # what the kernel itself counted: f64 atomic adds, 8 B each
+                    "framebuffer_atomic_bytes_per_launch": 24 * n_flush,
                     "note": "algorithmic bytes (event x record-size model, SURVEY 8(d)); the scene is L2/LDS-resident, "
                             "physical HBM traffic is ~ the framebuffer (see DESIGN.md / profiles/)"}
         out = {

@@ -160,6 +160,9 @@ int rt_last_kernel_ms(rt_scene*, float* ms_out);
  * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
  * that carried a live path ([2] / (64*[1]) = lane utilisation). */
 int rt_last_stats(rt_scene*, unsigned long long out3[3]);
+/* Per-pixel accumulator flushes of the most recent finished launch; each is three f64 atomic adds to the frame — the
+ * kernel's only global write traffic (used to calibrate the WRITE_SIZE counter). */
+int rt_last_flush_count(rt_scene*, unsigned long long* out);
 /* Scenes with a BVH (persistent-traversal kernel): [0] advance passes, [1] lanes taking part in them, [2] traversal
  * steps, [3] lanes stepping, all summed over wavefronts ([3] / (64*[2]) = lane utilisation of the traversal). */
 int rt_last_traversal_stats(rt_scene*, unsigned long long out4[4]);

@@ -502,6 +502,13 @@ int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {
     HIP_OK(hipMemcpy(out, sc->s.d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
+// Accumulator flushes of the last launch: each is three hardware f64 atomic adds to the frame (the kernel's only global writes)
+int rt_last_flush_count(rt_scene* sc, unsigned long long* out) {
+    if (!sc || !out || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
+    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
+    HIP_OK(hipMemcpy(out, (char*)sc->s.d_stats + 11 * sizeof(unsigned long long), sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
 // BVH scenes: {advance passes, lanes advancing, traversal steps, lanes stepping} summed over waves; zeros for list scenes
 int rt_last_traversal_stats(rt_scene* sc, unsigned long long out[4]) {
     if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");

@@ -99,7 +99,7 @@ template <typename T> struct KParams {
     uint32_t* queue;               // zeroed before launch
     double* out;                   // n_local_tiles * tile_px * 3 (always f64: per-pixel sums)
     double* samples_out;           // optional: local_px * spp * 3
-    unsigned long long* stats;     // [0] non-finite samples, [1] bounce iterations, [2] lane-iterations active, [9] traversal steps, [10] lanes stepping
+    unsigned long long* stats;     // [0] non-finite samples, [1] bounce iterations, [2] lane-iterations active, [9] traversal steps, [10] lanes stepping, [11] accumulator flushes (3 f64 atomics each)
     // BVH scenes (persistent traversal): a traversal pass starts once trav_hi lanes are inside a BVH and runs until fewer
     // than trav_lo are still walking
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf

@@ -811,7 +811,7 @@ DEV double wave_sum(double x) {                      // fixed butterfly: determi
 // Lanes with `need` set hold a partial per-pixel sum (acc) for local pixel acc_px.  All partials of one pixel are
 // combined by a masked butterfly and added to out[] by one lane with one f64 atomic per channel (a handful per pixel
 // per frame: this is the kernel's only global write traffic).
-DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out, uint32_t lane) {
+DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out, uint32_t lane, uint32_t& n_flush) {
     unsigned long long m = __ballot(need);
     while (m) {
         uint32_t leader = (uint32_t)__builtin_ctzll(m);
@@ -823,6 +823,7 @@ DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out,
         if (lane == leader) {
             double* o = out + (size_t)px * 3u;        // hardware f64 atomics: a pixel's samples may be split over several waves
             unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2);
+            n_flush++;
         }
         need = need && !mine;
         m = __ballot(need);
@@ -1069,9 +1070,10 @@ DEV void add_radiance(const KParams<T>& P, V3<T> L, double acc[3], uint32_t& n_n
         so[0] = l0; so[1] = l1; so[2] = l2;
     }
 }
-DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfinite, unsigned long long n_iters, unsigned long long n_active) {
+DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfinite, unsigned long long n_iters, unsigned long long n_active, uint32_t n_flush) {
     if (!stats) return;
     if (n_nonfinite) atomicAdd(&stats[0], (unsigned long long)n_nonfinite);
+    if (n_flush) atomicAdd(&stats[11], (unsigned long long)n_flush);
     unsigned long long a = n_active;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
@@ -1094,7 +1096,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
     double acc[3] = {0.0, 0.0, 0.0};
-    uint32_t n_nonfinite = 0;
+    uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0;
     DIAG_DECL
 
@@ -1107,7 +1109,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_ADD(0);
 
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane);
+        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
 
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
@@ -1149,8 +1151,8 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         }
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane);
-    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active);
+    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
+    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active, n_flush);
 #ifdef RT_DIAG
     if (P.stats && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.stats[3 + k], dg_sum[k]);
 #endif
@@ -1195,7 +1197,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
     double acc[3] = {0.0, 0.0, 0.0};
-    uint32_t n_nonfinite = 0;
+    uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0;
     DIAG_DECL
     DIAG_T0();
@@ -1312,7 +1314,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         uint32_t new_px = 0;
         const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane);
+        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
             path_px = new_px;
@@ -1341,8 +1343,8 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         DIAG_ADD(1);
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane);
-    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active);
+    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
+    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active, n_flush);
     if (P.stats) {
         unsigned long long a = n_step_lanes;
 #pragma unroll

@@ -81,6 +81,15 @@ def render_tiles_device(b: SceneBuilder, cam: CameraParams, background, W: int, 
         raise RenderError(_err(be))
 
 
+def last_flush_count(b: SceneBuilder) -> int:
+    """Accumulator flushes of the last launch (three f64 atomics to the frame each)."""
+    be = _lib.load()
+    out = C.c_ulonglong()
+    if be.lib.rt_last_flush_count(b.h, C.byref(out)) != 0:
+        raise RenderError(_err(be))
+    return int(out.value)
+
+
 def last_traversal_stats(b: SceneBuilder) -> dict:
     """BVH scenes: advance passes / traversal steps of the last launch and the lanes busy in each (summed over wavefronts)."""
     be = _lib.load()
