@@ -394,6 +394,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     if (const char* e = std::getenv("RT_AMD_TRAV_LO")) P.trav_lo = (uint32_t)std::atoi(e);
     if (P.trav_hi < 1u) P.trav_hi = 1u; if (P.trav_hi > 64u) P.trav_hi = 64u;
     if (P.trav_lo < 1u) P.trav_lo = 1u; if (P.trav_lo > P.trav_hi) P.trav_lo = P.trav_hi;
+    if (P.trav_leaf < 1u) P.trav_leaf = 1u; if (P.trav_leaf > 64u) P.trav_leaf = 64u;      // >= 1: a box step must win the vote when no leaf is pending
     uint64_t n_local_px = (uint64_t)P.n_local_tiles * tile_px;
     if (n_local_px >= 0xFFFFFFFFull) return set_err("too many local pixels");
     if ((size_t)n_local_px * 3 * sizeof(double) > d_out_bytes) return set_err("output buffer too small for n_local_tiles * tile_px * 3 doubles");
