@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--tile-px", type=int, default=67, help="pixels per tile; prime by default (see dist.DEFAULT_TILE_PX)")
     ap.add_argument("--f32", action="store_true", help="throughput variant (not the headline: reduced precision)")
     ap.add_argument("--near-first", action="store_true", help="opt-in RT_NEAR_FIRST_BVH traversal (not the reference's order)")
+    ap.add_argument("--sah", action="store_true", help="opt-in RT_BVH_SAH builder (not the reference's tree shape)")
     ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -103,6 +104,8 @@ def main():
         earth = (im.tobytes(), im.size[0], im.size[1])
     b, cam, bg = workloads.build(w, be, earth)
     flags = (R.RT_F32 if args.f32 else R.RT_F64) | (R.RT_NEAR_FIRST_BVH if args.near_first else 0)
+    if args.sah:
+        R.set_bvh_builder(b, R.RT_BVH_SAH)
     tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world)
 
     def sync():

@@ -150,6 +150,12 @@ int rt_render_device(rt_scene*, const rt_camera*, const double background[3], ui
                      uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
                      uint32_t tile_px, uint32_t rank, uint32_t world_size,
                      void* d_out, size_t d_out_bytes, void* hip_stream);
+/* How BVH objects are built when the scene is flattened (at the first render / rt_scene_prepare after a change).
+ * RT_BVH_MEDIAN (default) is BVH::new, src/bvh.rs:18-73: widest axis, object median.  RT_BVH_SAH is an opt-in fast mode
+ * (binned surface-area heuristic, one object per leaf as in the reference): same closest hits; the order in which
+ * exactly-equal-t hits are met, and last-ulp box culls, may differ — like RT_NEAR_FIRST_BVH. */
+enum rt_bvh_builder { RT_BVH_MEDIAN = 0, RT_BVH_SAH = 1 };
+int rt_scene_set_bvh_builder(rt_scene*, int mode);
 /* Optional: do now what the first render of this scene would do once inside its call (flatten, upload for the precision in
  * `flags`, load the kernel's code object).  Launches nothing. */
 int rt_scene_prepare(rt_scene*, uint32_t flags);

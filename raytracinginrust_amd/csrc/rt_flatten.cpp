@@ -149,6 +149,55 @@ struct Flattener {
         std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) {       // bvh.rs:19-31,51
             return (boxes[x].mn[axis] + boxes[x].mx[axis]) < (boxes[y].mn[axis] + boxes[y].mx[axis]);
         });
+        size_t n_lower = items.size() / 2;                                           // bvh.rs:65: the object median
+        // Opt-in builder (rt_scene_set_bvh_builder(RT_BVH_SAH)), not the reference's: binned surface-area heuristic.  Same
+        // node / leaf forms (one object per leaf), so the kernels do not care; only the tree's shape — and with it the order
+        // in which equal-t hits are met — differs.  Falls back to the median split when no SAH split separates the objects
+        // and near the depth limit (an SAH tree can be lopsided).
+        if (s.bvh_builder == 1 && items.size() > 2 && depth + 8 < (uint32_t)RT_MAX_BVH_DEPTH) {
+            auto area = [](const Box& b) {
+                double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+                return 2.0 * (dx * dy + dy * dz + dz * dx);
+            };
+            auto grow = [](Box& b, const Box& o) { for (int k = 0; k < 3; k++) { b.mn[k] = std::fmin(b.mn[k], o.mn[k]); b.mx[k] = std::fmax(b.mx[k], o.mx[k]); } };
+            const int NB = 16;
+            double best_cost = F64_MAX; int best_axis = -1, best_split = -1; double best_lo = 0, best_scale = 0;
+            for (int a = 0; a < 3; a++) {
+                double cmin = F64_MAX, cmax = -F64_MAX;
+                for (const Box& b : boxes) { double c = 0.5 * (b.mn[a] + b.mx[a]); cmin = std::fmin(cmin, c); cmax = std::fmax(cmax, c); }
+                if (!(cmax > cmin)) continue;
+                const double scale = NB / (cmax - cmin);
+                Box bb[NB]; size_t cnt[NB];
+                for (int i = 0; i < NB; i++) { cnt[i] = 0; for (int k = 0; k < 3; k++) { bb[i].mn[k] = F64_MAX; bb[i].mx[k] = -F64_MAX; } }
+                for (const Box& b : boxes) {
+                    int bi = (int)((0.5 * (b.mn[a] + b.mx[a]) - cmin) * scale); if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0;
+                    cnt[bi]++; grow(bb[bi], b);
+                }
+                double right_area[NB]; size_t right_cnt[NB];
+                Box acc; for (int k = 0; k < 3; k++) { acc.mn[k] = F64_MAX; acc.mx[k] = -F64_MAX; }
+                size_t c = 0;
+                for (int i = NB - 1; i >= 1; i--) { if (cnt[i]) grow(acc, bb[i]); c += cnt[i]; right_area[i] = c ? area(acc) : 0.0; right_cnt[i] = c; }
+                for (int k = 0; k < 3; k++) { acc.mn[k] = F64_MAX; acc.mx[k] = -F64_MAX; }
+                c = 0;
+                for (int i = 0; i < NB - 1; i++) {                  // split between bin i and i + 1
+                    if (cnt[i]) grow(acc, bb[i]);
+                    c += cnt[i];
+                    if (c == 0 || right_cnt[i + 1] == 0) continue;
+                    double cost = area(acc) * (double)c + right_area[i + 1] * (double)right_cnt[i + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = i; best_lo = cmin; best_scale = scale; }
+                }
+            }
+            if (best_axis >= 0) {
+                axis = best_axis;
+                std::vector<size_t> lo, hi;
+                for (size_t i = 0; i < boxes.size(); i++) {
+                    int bi = (int)((0.5 * (boxes[i].mn[axis] + boxes[i].mx[axis]) - best_lo) * best_scale); if (bi >= NB) bi = NB - 1; if (bi < 0) bi = 0;
+                    (bi <= best_split ? lo : hi).push_back(i);
+                }
+                n_lower = lo.size();
+                order = lo; order.insert(order.end(), hi.begin(), hi.end());
+            }
+        }
         uint32_t me = (uint32_t)f.bvh.size();
         out_index = me;
         f.bvh.push_back(DBvhNode<double>{});
@@ -165,8 +214,8 @@ struct Flattener {
             return true;
         }
         std::vector<int> lower, upper;
-        for (size_t i = 0; i < length / 2; i++) lower.push_back(items[order[i]]);
-        for (size_t i = length / 2; i < length; i++) upper.push_back(items[order[i]]);   // bvh.rs:65: drain(length/2..) -> right
+        for (size_t i = 0; i < n_lower; i++) lower.push_back(items[order[i]]);
+        for (size_t i = n_lower; i < length; i++) upper.push_back(items[order[i]]);      // bvh.rs:65: drain(length/2..) -> right
         uint32_t li, ri; Box lb, rb;
         if (!build_bvh(lower, depth + 1, li, lb)) return false;
         if (!build_bvh(upper, depth + 1, ri, rb)) return false;

@@ -69,6 +69,13 @@ static void touch(rt_scene* sc) {
     free_device_scene(sc->s.dev64);
     free_device_scene(sc->s.dev32);
 }
+int rt_scene_set_bvh_builder(rt_scene* sc, int mode) {
+    if (!sc) return set_err("null argument");
+    if (mode != RT_BVH_MEDIAN && mode != RT_BVH_SAH) return set_err("unknown BVH builder");
+    touch(sc);
+    sc->s.bvh_builder = mode;
+    return 0;
+}
 static bool tex_ok(rt_scene* sc, int t) { return t >= 0 && t < (int)sc->s.textures.size(); }
 static bool mat_ok(rt_scene* sc, int m) { return m >= 0 && m < (int)sc->s.materials.size(); }
 static bool node_ok(rt_scene* sc, int h) { return h >= 0 && h < (int)sc->s.nodes.size(); }

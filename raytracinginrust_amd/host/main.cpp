@@ -4,7 +4,7 @@
 // (same constructor names and argument order).  Usage mirrors `cargo run --release > image.ppm` (README.md:4):
 //
 //     rtrender [--scene cornell|random|final|teapot|two_sphere|two_perlin|earth|light_room|smoke|progress] [--width W] [--height H] [--spp N] [--depth D]
-//              [--seed S] [--obj teapot.obj] [--earth earth.ppm] [--f32] > image.ppm
+//              [--seed S] [--obj teapot.obj] [--earth earth.ppm] [--f32] [--fast-bvh] > image.ppm
 //
 // The reference hard-codes its settings as consts (main.rs:579-583, :623); they are flags here.
 #include <cstdio>
@@ -239,7 +239,7 @@ enum class SceneKind { Random, TwoSphere, TwoPerlinSphere, Earth, LightRoom, Cor
 int main(int argc, char** argv) {
     SceneKind scene = SceneKind::CornellBox;
     uint32_t image_width = 500, image_height = 500, samples_per_pixel = 800, max_depth = 100;    // main.rs:579-583
-    uint64_t seed = 0x5EED; uint32_t flags = RT_F64;
+    uint64_t seed = 0x5EED; uint32_t flags = RT_F64; bool fast_bvh = false;
     std::string obj_path = "teapot.obj", earth_path = "earthmap.jpg";       // the reference's asset names (main.rs:248,491)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -260,11 +260,13 @@ int main(int argc, char** argv) {
         else if (a == "--obj") obj_path = next();
         else if (a == "--earth") earth_path = next();
         else if (a == "--f32") flags |= RT_F32;
+        else if (a == "--fast-bvh") { fast_bvh = true; flags |= RT_NEAR_FIRST_BVH; }      // opt-in, not the reference's tree / visiting order
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
     const double aspect_ratio = (double)image_width / (double)image_height;
     try {
         Scene s;
+        if (fast_bvh && rt_scene_set_bvh_builder(s.raw(), RT_BVH_SAH) != 0) throw Error(rt_last_error());
         Color background; Camera camera;
         Vec3 vup(0.0, 1.0, 0.0);
         switch (scene) {                                                    // main.rs:624-765

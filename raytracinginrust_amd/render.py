@@ -39,6 +39,16 @@ def flatten(b: SceneBuilder) -> dict:
     return dict(zip(FLATTEN_COUNT_NAMES, [int(x) for x in counts]))
 
 
+RT_BVH_MEDIAN, RT_BVH_SAH = 0, 1
+
+
+def set_bvh_builder(b: SceneBuilder, mode: int) -> None:
+    """RT_BVH_MEDIAN: the reference's BVH::new (default); RT_BVH_SAH: opt-in binned surface-area heuristic."""
+    be = _lib.load()
+    if be.lib.rt_scene_set_bvh_builder(b.h, mode) != 0:
+        raise RenderError(_err(be))
+
+
 def prepare(b: SceneBuilder, flags: int = RT_F64) -> None:
     """Flatten, upload and load the kernel now instead of inside the first render (no launch)."""
     be = _lib.load()

@@ -95,6 +95,20 @@ def test_flatten_tables(pbe, earth):
     assert t["triangles"] == 1024 and t["bvh_nodes"] == 2047 and t["rects"] == 6
 
 
+def test_sah_builder_keeps_the_table_shapes(pbe, earth):
+    """The opt-in SAH builder only reshapes the tree: same leaves, same node count (one object per leaf), within the depth limit."""
+    for name in ("random", "final", "teapot"):
+        b = build_scene(name, pbe, earth)[0]
+        ref = R.flatten(b)
+        R.set_bvh_builder(b, R.RT_BVH_SAH)
+        sah = R.flatten(b)
+        assert sah == ref
+        R.set_bvh_builder(b, R.RT_BVH_MEDIAN)
+        assert R.flatten(b) == ref
+    with pytest.raises(R.RenderError):
+        R.set_bvh_builder(b, 7)
+
+
 def test_obj_loader_teapot():
     pos, idx = scenes.load_obj(scenes.asset_path("teapot.obj"), (0.0, 0.0, 0.0), 1.0)
     assert len(pos) == 530 and len(idx) == 3 * 1024 and max(idx) == 529 and min(idx) == 0

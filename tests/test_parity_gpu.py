@@ -354,6 +354,20 @@ def test_persistent_traversal_on_the_teapot_room(pbe):
     assert np.array_equal(a.view(np.uint64), c.view(np.uint64))
 
 
+@pytest.mark.parametrize("name", ["random", "final", "teapot"])
+def test_sah_builder_finds_the_same_hits(name, pbe, earth):
+    """RT_BVH_SAH changes the shape of the tree, not what a ray hits: per-sample agreement with the reference-shaped tree
+    (a sample may differ only through an exactly-equal-t tie or a last-ulp box cull, as with RT_NEAR_FIRST_BVH)."""
+    b, cam, bg = build_scene(name, pbe, earth)
+    W, H, spp, depth = 48, 48, 8, 12
+    _, ref = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    R.set_bvh_builder(b, R.RT_BVH_SAH)
+    for flags in (0, R.RT_NEAR_FIRST_BVH):
+        _, got = R.render(b, cam, bg, W, H, spp, depth, flags=flags, want_samples=True)
+        same = (got.view(np.uint64) == ref.view(np.uint64)).all(axis=-1)
+        assert same.mean() > 0.999, f"{name}: {int((~same).sum())} of {same.size} samples differ"
+
+
 def test_stop_on_zero_flag_is_equivalent_without_nans(pbe):
     b, cam, bg = _cornell(pbe)
     a = R.render(b, cam, bg, 64, 64, 32, 50)

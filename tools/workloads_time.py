@@ -11,6 +11,7 @@ for key in os.environ.get('RT_WORKLOADS', 'C1,C2,C3,C4').split(','):
     w = workloads.WORKLOADS[key]
     b, cam, bg = workloads.build(w, be, earth)
     s = min(spp, w.spp)
+    if os.environ.get('RT_BVH'): R.set_bvh_builder(b, int(os.environ['RT_BVH']))
     flags = int(os.environ.get('RT_FLAGS', '0'))
     for _ in range(2):
         out = R.render(b, cam, bg, w.W, w.H, s, w.max_depth, flags=flags)
