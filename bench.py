@@ -49,11 +49,16 @@ def pmc_traffic_bytes(workload_key):
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_bench_{workload_key}_pmc_summary.csv")))
     if not files:
-        return None, None
+        return None, None, None
     vals = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(files[-1]))}
     if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None, None
-    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.basename(files[-1])
+        return None, None, None
+    # secondary figure: fraction of SIMD time the vector ALU is busy.  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES
+    # both count quad-cycles summed over waves; SQ_WAVES / 1024 SIMDs = resident waves per SIMD of the persistent grid.
+    valu = None
+    if all(k in vals for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES")) and vals["SQ_WAVE_CYCLES"] > 0:
+        valu = vals["SQ_ACTIVE_INST_VALU"] * (vals["SQ_WAVES"] / 1024.0) / vals["SQ_WAVE_CYCLES"]
+    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.basename(files[-1]), valu
 
 
 def main():
@@ -154,11 +159,12 @@ def main():
         roof = None
         if bps is not None:
             achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
-            traffic, traffic_src = pmc_traffic_bytes(w.key) if (world == 1 and not args.f32) else (None, None)
+            traffic, traffic_src, valu_busy = pmc_traffic_bytes(w.key) if (world == 1 and not args.f32) else (None, None, None)
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                     "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": bps * local_samples, "kernel": f"rt::pathtrace_kernel<{'float' if args.f32 else 'double'}, FEATS> (FEATS = 0 for the Cornell box; the leanest instantiation covering the scene)",
                     "kernel_ms": k_ms, "bytes_per_sample": bps,
+                    "valu_busy_frac": valu_busy,        # from the same committed PMC passes: what actually limits the kernel
                     "framebuffer_atomics_per_launch": 3 * n_flush,       # what the kernel itself counted: f64 atomic adds, 8 B each
                     "framebuffer_atomic_bytes_per_launch": 24 * n_flush,
                     "note": "algorithmic bytes (event x record-size model, SURVEY 8(d)); the scene is L2/LDS-resident, "
