@@ -419,6 +419,56 @@ def test_full_size_cornell_properties(pbe, obe, orc_mod):
     print(f"C2 800x800x1024 f64: {ms:.1f} ms, {W * H * spp / ms / 1e3:.0f} Msamples/s")
 
 
+def test_full_size_teapot_properties(pbe, obe, orc_mod):
+    """BASELINE config 4 on one GPU: teapot room 1920x1080, 2048 spp, depth 50 (4.25 G samples).  (1) the persistent-traversal
+    loop (default here) and the lock-step loop give the same frame to summation-order rounding; (2) no non-finite sample;
+    (3) frame mean vs the oracle on a coarser grid of the same image; (4) 8 interleaved shards reassemble to the frame."""
+    import torch
+    from raytracinginrust_amd import workloads
+    w = workloads.WORKLOADS["C4"]
+    b, cam, bg = workloads.build(w, pbe)
+    a = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
+    ms = R.last_kernel_ms(b)
+    assert R.last_traversal_stats(b)["traversal_steps"] > 0 and R.last_stats(b)["nonfinite_samples"] == 0
+    c = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=R.RT_LOCKSTEP_BVH)
+    assert np.all(np.abs(a - c) <= 1e-12 * (w.spp + np.abs(a)))
+    del c
+    ob, ocam, obg = workloads.build(w, obe)
+    coarse = orc_mod.render(ob, ocam, obg, 160, 90, 32, w.max_depth, seed=11)
+    assert a.mean() / w.spp == pytest.approx(coarse.mean() / 32, rel=0.03)
+    parts = []
+    for rank in range(8):
+        tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, tile_px=D.DEFAULT_TILE_PX, rank=rank, world=8)
+        parts.append(tr.render_local().clone())
+    torch.cuda.synchronize()
+    frame = D.assemble(torch.stack(parts, 0), w.W, w.H, D.DEFAULT_TILE_PX).cpu().numpy()
+    assert np.all(np.abs(frame - a) <= 1e-12 * (w.spp + np.abs(a)))
+    print(f"C4 {w.W}x{w.H}x{w.spp} f64: {ms:.0f} ms, {w.samples / ms / 1e3:.0f} Msamples/s")
+
+
+def test_full_size_final_scene_properties(pbe, obe, orc_mod, earth):
+    """BASELINE config 3: final scene 800x800, 4096 spp, depth 50 (2.62 G samples).  Two runs agree to summation-order rounding
+    with the same pixels poisoned by non-finite samples (the reference's 0/0 cases), and the mean of the finite pixels matches
+    the oracle's on a coarser grid."""
+    from raytracinginrust_amd import workloads
+    w = workloads.WORKLOADS["C3"]
+    b, cam, bg = workloads.build(w, pbe, earth)
+    a = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
+    ms = R.last_kernel_ms(b)
+    n_bad = R.last_stats(b)["nonfinite_samples"]
+    c = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
+    assert R.last_stats(b)["nonfinite_samples"] == n_bad
+    assert np.array_equal(np.isfinite(a), np.isfinite(c))
+    fin = np.isfinite(a)
+    assert (~fin).any(axis=-1).sum() <= n_bad                    # every poisoned pixel holds at least one counted sample
+    assert np.all(np.abs(a[fin] - c[fin]) <= 1e-12 * (w.spp + np.abs(a[fin])))
+    ob, ocam, obg = workloads.build(w, obe, earth)
+    coarse = orc_mod.render(ob, ocam, obg, 100, 100, 32, w.max_depth, seed=13)
+    cf = np.isfinite(coarse)
+    assert a[fin].mean() / w.spp == pytest.approx(coarse[cf].mean() / 32, rel=0.05)
+    print(f"C3 {w.W}x{w.H}x{w.spp} f64: {ms:.0f} ms, {w.samples / ms / 1e3:.0f} Msamples/s, {n_bad} non-finite samples")
+
+
 def test_f32_variant_statistical_parity(pbe):
     """RT_F32 is the throughput variant: same estimator in f32, so only statistical agreement is claimed."""
     b, cam, bg = _cornell(pbe)
