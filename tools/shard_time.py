@@ -7,7 +7,7 @@ from raytracinginrust_amd import _lib, dist as D, render as R, scenes
 be = _lib.load(); b, cam, bg = scenes.cornell_box(be)
 W = H = 800; spp = 1024; depth = 50
 res = {}
-for world in (1, 2, 4, 8):
+for world in (1, 2, 4, 8, 16, 32, 64, 256):
     tr = D.TileRenderer(b, cam, bg, W, H, spp, depth, tile_px=64, rank=0, world=world)
     ts = []
     for _ in range(4):
