@@ -162,6 +162,10 @@ int rt_scene_prepare(rt_scene*, uint32_t flags);
 /* Milliseconds of the most recent path-tracing kernel launched by this library on this thread's scene,
  * from HIP events recorded on the launch stream (blocks until that kernel finishes). */
 int rt_last_kernel_ms(rt_scene*, float* ms_out);
+/* Total duration (ms, HIP events on the launch streams) and number of this scene's path-tracing kernels since the last
+ * reset; waits for launches still in flight.  Launches of one scene on different streams may overlap (up to four streams; a
+ * frame's drain then hides behind the next frame's start); launches on one stream are ordered by the stream. */
+int rt_kernel_time_total(rt_scene*, double* ms_total, unsigned long long* n_launches, int reset);
 /* Counters of the most recent finished launch: [0] samples whose radiance was not finite (the reference's
  * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
  * that carried a live path ([2] / (64*[1]) = lane utilisation). */

@@ -57,9 +57,12 @@ void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
     free_device_scene(sc->s.dev64);
     free_device_scene(sc->s.dev32);
-    free_dev(sc->s.d_queue); free_dev(sc->s.d_stats);
-    if (sc->s.ev_start) (void)hipEventDestroy((hipEvent_t)sc->s.ev_start);
-    if (sc->s.ev_stop) (void)hipEventDestroy((hipEvent_t)sc->s.ev_stop);
+    for (Scene::LaunchSlot& l : sc->s.slots) {
+        if (l.recorded) (void)hipEventSynchronize((hipEvent_t)l.ev_stop);
+        free_dev(l.d_queue); free_dev(l.d_stats);
+        if (l.ev_start) (void)hipEventDestroy((hipEvent_t)l.ev_start);
+        if (l.ev_stop) (void)hipEventDestroy((hipEvent_t)l.ev_stop);
+    }
     delete sc;
 }
 const char* rt_scene_error(rt_scene* sc) { return sc->s.error.c_str(); }
@@ -354,6 +357,33 @@ template <typename T> DeviceScene<T>& dev_of(Scene& s);
 template <> DeviceScene<double>& dev_of<double>(Scene& s) { return s.dev64; }
 template <> DeviceScene<float>& dev_of<float>(Scene& s) { return s.dev32; }
 
+// A finished launch's kernel time joins the running total exactly once (rt_kernel_time_total).
+static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
+    if (!l.recorded || l.timed) return 0;
+    HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
+    s.kernel_ms_total += ms; s.kernel_launches_timed++;
+    l.timed = true;
+    return 0;
+}
+// The launch slot for `stream`: the one this stream used last, else an unused one, else the least recently used one once its
+// launch has finished.
+static int acquire_slot(Scene& s, hipStream_t stream, Scene::LaunchSlot** out) {
+    Scene::LaunchSlot* pick = nullptr;
+    for (Scene::LaunchSlot& l : s.slots) if (l.recorded && l.stream == (void*)stream) { pick = &l; break; }
+    if (!pick) for (Scene::LaunchSlot& l : s.slots) if (!l.recorded) { pick = &l; break; }
+    if (!pick) { pick = &s.slots[0]; for (Scene::LaunchSlot& l : s.slots) if (l.seq < pick->seq) pick = &l; }
+    if (settle_slot(s, *pick)) return -1;             // also waits for a launch another stream may still be running in this slot
+    if (!pick->d_queue) HIP_OK(hipMalloc(&pick->d_queue, 64));
+    if (!pick->d_stats) HIP_OK(hipMalloc(&pick->d_stats, RT_STATS_BYTES));
+    if (!pick->ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); pick->ev_start = e; }
+    if (!pick->ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); pick->ev_stop = e; }
+    pick->stream = (void*)stream;
+    *out = pick;
+    return 0;
+}
+
 // Loop shape for mesh scenes (same samples either way): a triangle-mesh BVH that stands beside other top-level objects is
 // entered by a minority of the rays, which is where persistent traversal pays (measured +20 % on the teapot room); when
 // every ray walks the BVH (the BVH is the world) the lock-step loop is faster.
@@ -411,11 +441,9 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     if (spp >= 2u * CH) { P.chunk_px = 1u; P.chunks_per_px = (spp + CH - 1) / CH; P.chunk_spp = (spp + P.chunks_per_px - 1) / P.chunks_per_px; }
     else { P.chunk_px = (CH + spp - 1) / spp; P.chunks_per_px = 1u; P.chunk_spp = spp; }
     P.n_coarse_px = 0;
-    if (!s.d_queue) HIP_OK(hipMalloc(&s.d_queue, 64));
-    if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 128));
-    if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
-    if (!s.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_stop = e; }
-    P.queue = (uint32_t*)s.d_queue; P.stats = (unsigned long long*)s.d_stats;
+    Scene::LaunchSlot* slot = nullptr;
+    if (acquire_slot(s, stream, &slot)) return -1;
+    P.queue = (uint32_t*)slot->d_queue; P.stats = (unsigned long long*)slot->d_stats;
     P.out = (double*)d_out; P.samples_out = (double*)d_samples;
 
     int dev = 0; HIP_OK(hipGetDevice(&dev));
@@ -438,13 +466,14 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         P.n_chunks = (uint32_t)n_chunks64;
     }
 
-    HIP_OK(hipMemsetAsync(s.d_queue, 0, 64, stream));
-    HIP_OK(hipMemsetAsync(s.d_stats, 0, 128, stream));
+    HIP_OK(hipMemsetAsync(slot->d_queue, 0, 64, stream));
+    HIP_OK(hipMemsetAsync(slot->d_stats, 0, RT_STATS_BYTES, stream));
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)n_local_px * 3 * sizeof(double), stream));
-    HIP_OK(hipEventRecord((hipEvent_t)s.ev_start, stream));
+    HIP_OK(hipEventRecord((hipEvent_t)slot->ev_start, stream));
     HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
-    HIP_OK(hipEventRecord((hipEvent_t)s.ev_stop, stream));
-    s.ev_recorded = true;
+    HIP_OK(hipEventRecord((hipEvent_t)slot->ev_stop, stream));
+    slot->recorded = true; slot->timed = false; slot->seq = ++s.launch_seq;
+    s.last_slot = (int)(slot - s.slots);
     return 0;
 }
 
@@ -484,10 +513,12 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     Scene& s = sc->s;
     if (flags & RT_F32) { if (ensure_uploaded<float>(s, s.dev32)) return -1; }
     else { if (ensure_uploaded<double>(s, s.dev64)) return -1; }
-    if (!s.d_queue) HIP_OK(hipMalloc(&s.d_queue, 64));
-    if (!s.d_stats) HIP_OK(hipMalloc(&s.d_stats, 128));
-    if (!s.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_start = e; }
-    if (!s.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); s.ev_stop = e; }
+    for (Scene::LaunchSlot& l : s.slots) {
+        if (!l.d_queue) HIP_OK(hipMalloc(&l.d_queue, 64));
+        if (!l.d_stats) HIP_OK(hipMalloc(&l.d_stats, RT_STATS_BYTES));
+        if (!l.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_start = e; }
+        if (!l.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_stop = e; }
+    }
     size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * s.flat.bvh_depth * 64 * sizeof(uint32_t);
     const uint32_t eff = effective_flags(s.flat, flags);
     int bpc = (flags & RT_F32) ? pathtrace_blocks_per_cu<float>(s.flat.feats, eff, shmem) : pathtrace_blocks_per_cu<double>(s.flat.feats, eff, shmem);
@@ -497,40 +528,61 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
 }
 
 int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
-    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
-    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
-    HIP_OK(hipEventElapsedTime(ms_out, (hipEvent_t)sc->s.ev_start, (hipEvent_t)sc->s.ev_stop));
+    if (!sc || !ms_out || sc->s.last_slot < 0) return set_err("no kernel has been launched for this scene");
+    Scene::LaunchSlot& l = sc->s.slots[sc->s.last_slot];
+    HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
+    HIP_OK(hipEventElapsedTime(ms_out, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
     return 0;
 }
 
 // [0] non-finite samples, [1] wave bounce-loop iterations, [2] lane-iterations with a live path  (last finished launch)
+// Sum of the path-tracing kernels' durations (HIP events on their launch streams) and their number since the last reset; waits
+// for the launches still in flight.  For callers that keep several frames in flight and must not stop after each one.
+int rt_kernel_time_total(rt_scene* sc, double* ms_total, unsigned long long* n_launches, int reset) {
+    if (!sc) return set_err("null argument");
+    for (Scene::LaunchSlot& l : sc->s.slots) if (settle_slot(sc->s, l)) return -1;
+    if (ms_total) *ms_total = sc->s.kernel_ms_total;
+    if (n_launches) *n_launches = sc->s.kernel_launches_timed;
+    if (reset) { sc->s.kernel_ms_total = 0.0; sc->s.kernel_launches_timed = 0; }
+    return 0;
+}
+// The kernel spreads its end-of-launch counter atomics over RT_STATS_ROWS copies of the counter block (row = block index mod
+// rows): 4096 waves adding to one address serialise in the L2 atomic unit.  Readers sum the rows.
+static int read_stats(rt_scene* sc, unsigned long long h[RT_STATS_SLOTS]) {
+    if (!sc || sc->s.last_slot < 0) return set_err("no kernel has been launched for this scene");
+    Scene::LaunchSlot& l = sc->s.slots[sc->s.last_slot];
+    HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
+    unsigned long long raw[RT_STATS_ROWS * RT_STATS_SLOTS];
+    HIP_OK(hipMemcpy(raw, l.d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < RT_STATS_SLOTS; k++) { h[k] = 0; for (uint32_t r = 0; r < RT_STATS_ROWS; r++) h[k] += raw[r * RT_STATS_SLOTS + k]; }
+    return 0;
+}
 int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {
-    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
-    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
-    HIP_OK(hipMemcpy(out, sc->s.d_stats, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long h[RT_STATS_SLOTS];
+    if (read_stats(sc, h)) return -1;
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
     return 0;
 }
 // Accumulator flushes of the last launch: each is three hardware f64 atomic adds to the frame (the kernel's only global writes)
 int rt_last_flush_count(rt_scene* sc, unsigned long long* out) {
-    if (!sc || !out || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
-    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
-    HIP_OK(hipMemcpy(out, (char*)sc->s.d_stats + 11 * sizeof(unsigned long long), sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (!out) return set_err("null argument");
+    unsigned long long h[RT_STATS_SLOTS];
+    if (read_stats(sc, h)) return -1;
+    *out = h[11];
     return 0;
 }
 // BVH scenes: {advance passes, lanes advancing, traversal steps, lanes stepping} summed over waves; zeros for list scenes
 int rt_last_traversal_stats(rt_scene* sc, unsigned long long out[4]) {
-    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
-    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
-    unsigned long long h[16];
-    HIP_OK(hipMemcpy(h, sc->s.d_stats, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long h[RT_STATS_SLOTS];
+    if (read_stats(sc, h)) return -1;
     out[0] = h[1]; out[1] = h[2]; out[2] = h[9]; out[3] = h[10];
     return 0;
 }
 // diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections; zeros otherwise
 int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[6]) {
-    if (!sc || !sc->s.ev_recorded) return set_err("no kernel has been launched for this scene");
-    HIP_OK(hipEventSynchronize((hipEvent_t)sc->s.ev_stop));
-    HIP_OK(hipMemcpy(out, (char*)sc->s.d_stats + 3 * sizeof(unsigned long long), 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long h[RT_STATS_SLOTS];
+    if (read_stats(sc, h)) return -1;
+    for (int k = 0; k < 6; k++) out[k] = h[3 + k];
     return 0;
 }
 

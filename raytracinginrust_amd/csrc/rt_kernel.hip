@@ -862,6 +862,22 @@ template <typename T> DEV void locate(const KParams<T>& P, WaveWork& w) {   // l
     w.cur_i = w.cur_gp - row * P.W;
     w.cur_j = P.H - 1u - row;           // row 0 is j = H-1, main.rs:772
 }
+// Point the cursor at work chunk c (KParams: whole pixels first, then pieces of chunk_spp samples of one pixel).
+template <typename T> DEV void take_chunk(const KParams<T>& P, WaveWork& w, uint32_t c) {
+    const uint32_t n_local_px = P.n_local_tiles * P.tile_px;
+    if (c < P.n_coarse_px) {                      // a whole pixel
+        w.cur_px = c; w.end_px = c + 1u; w.s_lo = 0u; w.s_hi = P.spp;
+    } else {
+        const uint32_t c2 = c - P.n_coarse_px;
+        const uint32_t cp = c2 / P.chunks_per_px, sub = c2 - cp * P.chunks_per_px;
+        w.cur_px = P.n_coarse_px + cp * P.chunk_px;
+        w.end_px = w.cur_px + P.chunk_px; if (w.end_px > n_local_px) w.end_px = n_local_px;
+        w.s_lo = sub * P.chunk_spp;
+        w.s_hi = w.s_lo + P.chunk_spp; if (w.s_hi > P.spp) w.s_hi = P.spp;
+    }
+    w.cur_s = w.s_lo;
+    locate(P, w);
+}
 // Refill the queue: the next (up to) 64 samples of the cursor, all lanes generating (main.rs:813-820).  False when the
 // global work queue is exhausted and nothing was generated.
 template <typename T>
@@ -877,18 +893,7 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
             if (lane == 0) c = atomicAdd(P.queue, 1u);
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
             if (c >= P.n_chunks) { w.queue_done = true; break; }
-            if (c < P.n_coarse_px) {                      // a whole pixel
-                w.cur_px = c; w.end_px = c + 1u; w.s_lo = 0u; w.s_hi = P.spp;
-            } else {
-                const uint32_t c2 = c - P.n_coarse_px;
-                const uint32_t cp = c2 / P.chunks_per_px, sub = c2 - cp * P.chunks_per_px;
-                w.cur_px = P.n_coarse_px + cp * P.chunk_px;
-                w.end_px = w.cur_px + P.chunk_px; if (w.end_px > n_local_px) w.end_px = n_local_px;
-                w.s_lo = sub * P.chunk_spp;
-                w.s_hi = w.s_lo + P.chunk_spp; if (w.s_hi > P.spp) w.s_hi = P.spp;
-            }
-            w.cur_s = w.s_lo;
-            locate(P, w);
+            take_chunk(P, w, c);
         }
         if (w.cur_gp >= n_px || w.s_lo >= w.s_hi) { w.cur_px++; w.cur_s = w.s_lo; if (w.cur_px != w.end_px) locate(P, w); continue; }   // padding pixel / empty range
         uint32_t avail = w.s_hi - w.cur_s;
@@ -1070,6 +1075,12 @@ DEV void add_radiance(const KParams<T>& P, V3<T> L, double acc[3], uint32_t& n_n
         so[0] = l0; so[1] = l1; so[2] = l2;
     }
 }
+DEV unsigned long long* stats_row(unsigned long long* stats) {     // one of the RT_STATS_ROWS copies of the counter block (rt_launch.h)
+    // row from the CU / shader-array / shader-engine bits of HW_REG_HW_ID (bits 8..15): read here, at the very end of the
+    // kernel, so that nothing (such as the block index) has to stay alive through the main loop for it
+    const uint32_t where = (uint32_t)__builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);
+    return stats ? stats + (where % RT_STATS_ROWS) * RT_STATS_SLOTS : stats;
+}
 DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfinite, unsigned long long n_iters, unsigned long long n_active, uint32_t n_flush) {
     if (!stats) return;
     if (n_nonfinite) atomicAdd(&stats[0], (unsigned long long)n_nonfinite);
@@ -1152,9 +1163,10 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     }
     // ---- the queue is empty: hand in what is left
     flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
-    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active, n_flush);
+    unsigned long long* const st = stats_row(P.stats);
+    write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
 #ifdef RT_DIAG
-    if (P.stats && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.stats[3 + k], dg_sum[k]);
+    if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
 }
 
@@ -1344,14 +1356,15 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
     }
     // ---- the queue is empty: hand in what is left
     flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
-    write_stats(P.stats, lane, n_nonfinite, n_iters, n_active, n_flush);
-    if (P.stats) {
+    unsigned long long* const st = stats_row(P.stats);
+    write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
+    if (st) {
         unsigned long long a = n_step_lanes;
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-        if (lane == 0) { atomicAdd(&P.stats[9], n_steps); atomicAdd(&P.stats[10], a); }
+        if (lane == 0) { atomicAdd(&st[9], n_steps); atomicAdd(&st[10], a); }
 #ifdef RT_DIAG
-        if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&P.stats[3 + k], dg_sum[k]);
+        if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
     }
 }

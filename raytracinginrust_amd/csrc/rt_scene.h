@@ -59,10 +59,19 @@ struct Scene {
     HostFlat flat;
     DeviceScene<double> dev64;
     DeviceScene<float> dev32;
-    // launch scratch (device): queue counter, stats, events
-    void* d_queue = nullptr; void* d_stats = nullptr;
-    void* ev_start = nullptr; void* ev_stop = nullptr; bool ev_recorded = false;
-    unsigned long long last_stats[4] = {0, 0, 0, 0};
+    // Launch scratch (device queue counter + counter block, a pair of events), one set per stream in use: launches of one
+    // scene on different streams may overlap (a frame's drain with the next frame's start), launches on one stream are
+    // ordered by the stream.  A slot is bound to the stream that used it last; when all are bound to other streams the
+    // least recently used one is waited for and rebound.
+    static const int N_SLOTS = 4;
+    struct LaunchSlot {
+        void* d_queue = nullptr; void* d_stats = nullptr;
+        void* ev_start = nullptr; void* ev_stop = nullptr;
+        void* stream = nullptr; bool recorded = false, timed = true; unsigned long long seq = 0;
+    } slots[N_SLOTS];
+    int last_slot = -1;                    // slot of the most recent launch (what rt_last_* report)
+    unsigned long long launch_seq = 0;
+    double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
 
     void invalidate() { flat_valid = false; }
 };

@@ -91,6 +91,15 @@ def render_tiles_device(b: SceneBuilder, cam: CameraParams, background, W: int, 
         raise RenderError(_err(be))
 
 
+def kernel_time_total(b: SceneBuilder, reset: bool = False):
+    """(total ms, launches) of this scene's kernels since the last reset; waits for launches in flight."""
+    be = _lib.load()
+    ms, n = C.c_double(), C.c_ulonglong()
+    if be.lib.rt_kernel_time_total(b.h, C.byref(ms), C.byref(n), 1 if reset else 0) != 0:
+        raise RenderError(_err(be))
+    return float(ms.value), int(n.value)
+
+
 def last_flush_count(b: SceneBuilder) -> int:
     """Accumulator flushes of the last launch (three f64 atomics to the frame each)."""
     be = _lib.load()

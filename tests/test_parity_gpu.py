@@ -392,6 +392,27 @@ def test_tile_sharded_render_reassembles_to_full_frame(pbe, world, tile_px):
 
 
 # ------------------------------------------------------------------ BASELINE's full size: size-independent properties
+def test_two_frames_in_flight_give_the_same_frames(pbe):
+    """TileRenderer(pipeline=2): consecutive frames alternate between two streams / buffers / launch slots of one scene."""
+    import torch
+    b, cam, bg = _cornell(pbe)
+    W, H, spp, depth = 96, 80, 32, 20
+    one = D.TileRenderer(b, cam, bg, W, H, spp, depth, rank=0, world=1, pipeline=1)
+    ref = one.render_frame().clone(); one.sync()
+    two = D.TileRenderer(b, cam, bg, W, H, spp, depth, rank=0, world=1, pipeline=2)
+    R.kernel_time_total(b, reset=True)
+    frames = []
+    for i in range(5):
+        f = two.render_frame()                         # valid once its own stream is done: copy it on that stream
+        with torch.cuda.stream(two.streams[i % 2]):
+            frames.append(f.clone())
+    two.sync()
+    ms, n = R.kernel_time_total(b)
+    assert n == 5 and ms > 0.0
+    for f in frames:
+        assert torch.allclose(f, ref, rtol=1e-12, atol=1e-12 * spp, equal_nan=True)
+
+
 def test_full_size_cornell_properties(pbe, obe, orc_mod):
     """BASELINE config 2: Cornell box 800x800, 1024 spp, depth 50.  The oracle cannot run this in seconds, so:
     (1) two runs agree to summation-order rounding (the dynamic sample->lane assignment changes only the order);
