@@ -61,9 +61,9 @@ class TileRenderer:
 
     `pipeline` = frames kept in flight (1 or 2).  With 2, consecutive frames alternate between two HIP streams and two tile
     buffers, so that the start of frame i+1 overlaps the drain of frame i (a persistent launch spends ~0.5 ms filling up and
-    emptying out, *measured*: 16.15 -> 15.71 ms per 1/8 share of the C2 frame — when the runtime puts the two streams on different
-    hardware queues, which it does not always do; no gain at whole-frame size); the gather of frame i is ordered after its own
-    kernel on its own stream.  A returned frame is valid once that stream is done: call `sync()` (or synchronise the device)
+    emptying out, *measured*: 16.17 -> 15.73 ms per 1/8 share of the C2 frame, 4.41 -> 4.08 ms per 1/32; no gain at whole-frame
+    size); the gather of frame i is ordered after its own kernel on its own stream.  Not the bench default: with a real gather the
+    collective's kernels have to find CU room beside a persistent kernel that fills the chip, which was not measurable on one GPU.  A returned frame is valid once that stream is done: call `sync()` (or synchronise the device)
     before reading it, and copy it if it must outlive the next `pipeline` frames."""
 
     def __init__(self, builder, cam, background, W, H, spp, max_depth, seed=0x5EED, flags=R.RT_F64, tile_px=DEFAULT_TILE_PX,
@@ -79,7 +79,9 @@ class TileRenderer:
         self.pipeline = pipeline
         self.locals = [torch.empty((self.n_local, tile_px, 3), dtype=torch.float64, device=self.device) for _ in range(pipeline)]
         self.local = self.locals[0]
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(pipeline)] if pipeline > 1 else []
+        # different priorities = different hardware queues: with two equal-priority streams the runtime sometimes put both on one
+        # queue and the launches did not overlap at all (measured)
+        self.streams = [torch.cuda.Stream(self.device, priority=-(k % 2)) for k in range(pipeline)] if pipeline > 1 else []
         self.frames = 0
 
     def render_local(self, buf=None) -> torch.Tensor:
