@@ -24,14 +24,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def usable_cores():
+    """Threads this process can really run at once: hardware threads, CPU affinity and the cgroup CPU quota (a GPU box's
+    container sees every hardware thread of the host but is throttled to its share)."""
+    from oracle import orc
+    n = min(orc.hardware_threads(), len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                 # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())               # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, int(quota / period + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(w, sample_spp, earth=None):
-    """CPU restatement of the reference (oracle/), all host threads, on the workload's own pixel grid at
-    `sample_spp` samples per pixel.  Also returns the oracle's algorithmic bytes/sample for this workload."""
+    """CPU restatement of the reference (oracle/), all host threads, on the workload's own pixel grid.  `sample_spp` > 0 fixes
+    the samples per pixel of the bounded sample; -1 sizes it for about 8 s of wall time from a 1-spp calibration pass.
+    Also returns the oracle's algorithmic bytes/sample for this workload."""
     from oracle import orc
     from raytracinginrust_amd import workloads
     be = orc.load()
     b, cam, bg = workloads.build(w, be, earth)
-    threads = min(orc.hardware_threads(), len(os.sched_getaffinity(0)))      # the cores this process may actually use
+    threads = usable_cores()
+    if sample_spp < 0:
+        t = time.perf_counter()
+        orc.render(b, cam, bg, w.W, w.H, 1, w.max_depth, nthreads=threads, mode=0)
+        per_spp = max(time.perf_counter() - t, 1e-3)
+        sample_spp = int(min(256, max(4, round(8.0 / per_spp))))
     t = time.perf_counter()
     _, cnt = orc.render(b, cam, bg, w.W, w.H, sample_spp, w.max_depth, want_counters=True, nthreads=threads, mode=0)
     dt = time.perf_counter() - t
@@ -74,7 +100,7 @@ def main():
                     help="frames in flight; 2 lets a frame's drain overlap the next frame's start on a second stream (measured: -3 %% per "
                          "1/8-frame share when the two streams land on different hardware queues, nothing otherwise; off by default)")
     ap.add_argument("--sah", action="store_true", help="opt-in RT_BVH_SAH builder (not the reference's tree shape)")
-    ap.add_argument("--cpu-spp", type=int, default=16, help="spp of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-spp", type=int, default=-1, help="spp of the bounded CPU-baseline sample (0 = skip, -1 = sized for ~8 s of wall time)")
     args = ap.parse_args()
 
     import torch
@@ -156,7 +182,7 @@ def main():
         mean_radiance = float(torch.nan_to_num(frame).mean().item()) / w.spp
         value = w.samples * args.steps / elapsed / 1e6
         cpu, bps = None, workloads.BYTES_PER_SAMPLE.get(w.key)
-        if world == 1 and args.cpu_spp > 0 and not args.f32:
+        if world == 1 and args.cpu_spp != 0 and not args.f32:
             cpu, bps = cpu_baseline(w, args.cpu_spp, earth)
         k_ms = k_total_ms / k_launches
         n_px = w.W * w.H                     # real (unpadded) pixels rank 0's launch owns
