@@ -66,6 +66,8 @@ public:
         chk(rt_scene_set_world(s_, world.id));
         for (auto l : lights) chk(rt_lights_push(s_, l.id));
     }
+    // not in the reference: opt-in SAH tree for `BVH::new_` (default: the reference's widest-axis object-median split, bvh.rs:18-73)
+    void set_bvh_builder(rt_bvh_builder mode) { if (rt_scene_set_bvh_builder(s_, (int)mode) != 0) throw Error(rt_last_error()); }
 private:
     rt_scene* s_;
 };

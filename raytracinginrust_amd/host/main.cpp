@@ -266,7 +266,7 @@ int main(int argc, char** argv) {
     const double aspect_ratio = (double)image_width / (double)image_height;
     try {
         Scene s;
-        if (fast_bvh && rt_scene_set_bvh_builder(s.raw(), RT_BVH_SAH) != 0) throw Error(rt_last_error());
+        if (fast_bvh) s.set_bvh_builder(RT_BVH_SAH);
         Color background; Camera camera;
         Vec3 vup(0.0, 1.0, 0.0);
         switch (scene) {                                                    // main.rs:624-765
