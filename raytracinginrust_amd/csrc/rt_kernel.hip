@@ -14,6 +14,9 @@
 //     rebuilt once per bounce with per-lane gathers.  BVH traversal is per-lane with its stack staged in LDS.
 //   * per-pixel sums stay in registers (one accumulator per lane); when a lane moves to another pixel the partial sums of
 //     one pixel are combined by a masked wave butterfly and added to the frame with one hardware f64 atomic per channel.
+//   * two loop shapes: list scenes run the bounce loop in lock-step (every lane's closest-hit search costs the same); mesh scenes
+//     whose BVH stands beside other objects run a resumable search with persistent traversal (trace_resumable: lanes keep their
+//     place inside the BVH while the rest of the wave shades / regenerates) — same samples, different scheduling.
 //   * no MFMA: there is no dense contraction anywhere on this path.
 //
 // Arithmetic follows the reference expression by expression (cited inline) and is compiled with
