@@ -109,6 +109,14 @@ def test_sah_builder_keeps_the_table_shapes(pbe, earth):
         R.set_bvh_builder(b, 7)
 
 
+def test_launch_bookkeeping_before_any_launch(pbe):
+    b = build_scene("cornell", pbe)[0]
+    assert R.kernel_time_total(b) == (0.0, 0)                     # nothing launched, nothing to wait for
+    for query in (R.last_stats, R.last_flush_count, R.last_traversal_stats, R.last_kernel_ms):
+        with pytest.raises(R.RenderError):
+            query(b)
+
+
 def test_obj_loader_teapot():
     pos, idx = scenes.load_obj(scenes.asset_path("teapot.obj"), (0.0, 0.0, 0.0), 1.0)
     assert len(pos) == 530 and len(idx) == 3 * 1024 and max(idx) == 529 and min(idx) == 0
