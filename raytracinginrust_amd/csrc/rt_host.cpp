@@ -426,9 +426,6 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.tile_px = tile_px; P.rank = rank; P.world = world;
     P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
     P.trav_hi = 48u; P.trav_lo = 32u; P.trav_leaf = 16u;      // measured best on the teapot room (tools/workloads_time.py sweeps)
-    if (const char* e = std::getenv("RT_AMD_TRAV_LEAF")) P.trav_leaf = (uint32_t)std::atoi(e);
-    if (const char* e = std::getenv("RT_AMD_TRAV_HI")) P.trav_hi = (uint32_t)std::atoi(e);      // tuning knobs (tools/ only)
-    if (const char* e = std::getenv("RT_AMD_TRAV_LO")) P.trav_lo = (uint32_t)std::atoi(e);
     if (P.trav_hi < 1u) P.trav_hi = 1u; if (P.trav_hi > 64u) P.trav_hi = 64u;
     if (P.trav_lo < 1u) P.trav_lo = 1u; if (P.trav_lo > P.trav_hi) P.trav_lo = P.trav_hi;
     if (P.trav_leaf < 1u) P.trav_leaf = 1u; if (P.trav_leaf > 64u) P.trav_leaf = 64u;      // >= 1: a box step must win the vote when no leaf is pending
