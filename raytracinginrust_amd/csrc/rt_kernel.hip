@@ -29,6 +29,15 @@
 #include "rt_rng.h"
 #include "rt_launch.h"
 
+// The kernels are built as two translation units from this one source (csrc/Makefile): RT_TU == 1 holds the lean (list-scene)
+// kernels, RT_TU == 2 all the others; RT_TU == 0 (tools/mkvariant.sh) keeps everything together.  The split lets a code-generation
+// choice differ between them: the shared-denominator Vec3 division below pays in the 168-VGPR kernels (*measured* +3.8 % teapot
+// room, +1.7 % final scene) and costs the 128-VGPR lean kernel four more spilled registers (-1.2 % on the Cornell box).
+#ifndef RT_TU
+#define RT_TU 0
+#endif
+#define RT_SHARED_DIV3 (RT_TU == 2)
+
 namespace rt {
 
 // ------------------------------------------------------------------ small vector algebra (src/vec.rs)
@@ -40,7 +49,39 @@ template <typename T> DEV V3<T> operator-(V3<T> a, V3<T> b) { return mk<T>(a.x -
 template <typename T> DEV V3<T> operator*(V3<T> a, V3<T> b) { return mk<T>(a.x * b.x, a.y * b.y, a.z * b.z); }
 template <typename T> DEV V3<T> operator*(V3<T> a, T s) { return mk<T>(a.x * s, a.y * s, a.z * s); }
 template <typename T> DEV V3<T> operator*(T s, V3<T> a) { return mk<T>(s * a.x, s * a.y, s * a.z); }
-template <typename T> DEV V3<T> operator/(V3<T> a, T s) { return mk<T>(a.x / s, a.y / s, a.z / s); }
+// Vec3 / f64 (vec.rs:186-190) = three IEEE divisions by one denominator.  The compiler expands each `/` into the same
+// sequence (v_div_scale x2, v_rcp, two Newton steps, v_div_fmas, v_div_fixup); the denominator's part of it — scaling,
+// reciprocal, refinement — is identical for the three whenever v_div_scale leaves the denominator at the same value for all
+// three numerators (it rescales only at the ends of the exponent range).  Then it is computed once and each quotient
+// finishes with its own numerator: the same instructions on the same values, bit for bit the three separate divisions.
+// Otherwise (checked) the three plain divisions run.
+DEV V3<double> operator/(V3<double> a, double d) {
+#if !RT_SHARED_DIV3
+    return mk<double>(a.x / d, a.y / d, a.z / d);
+#else
+    bool fx, fy, fz, unused;
+    const double d0 = __builtin_amdgcn_div_scale(a.x, d, false, &unused);
+    const double d1 = __builtin_amdgcn_div_scale(a.y, d, false, &unused);
+    const double d2 = __builtin_amdgcn_div_scale(a.z, d, false, &unused);
+    if (__double_as_longlong(d0) == __double_as_longlong(d1) && __double_as_longlong(d0) == __double_as_longlong(d2)) {
+        const double nd = -d0;
+        double r = __builtin_amdgcn_rcp(d0);
+        r = __builtin_fma(r, __builtin_fma(nd, r, 1.0), r);
+        r = __builtin_fma(r, __builtin_fma(nd, r, 1.0), r);
+        const double nx = __builtin_amdgcn_div_scale(a.x, d, true, &fx);
+        const double ny = __builtin_amdgcn_div_scale(a.y, d, true, &fy);
+        const double nz = __builtin_amdgcn_div_scale(a.z, d, true, &fz);
+        const double qx = nx * r, qy = ny * r, qz = nz * r;
+        V3<double> o;
+        o.x = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nd, qx, nx), r, qx, fx), d, a.x);
+        o.y = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nd, qy, ny), r, qy, fy), d, a.y);
+        o.z = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(__builtin_fma(nd, qz, nz), r, qz, fz), d, a.z);
+        return o;
+    }
+    return mk<double>(a.x / d, a.y / d, a.z / d);
+#endif
+}
+DEV V3<float> operator/(V3<float> a, float s) { return mk<float>(a.x / s, a.y / s, a.z / s); }
 template <typename T> DEV T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                  // vec.rs:38-40
 template <typename T> DEV V3<T> cross(V3<T> a, V3<T> b) { return mk<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }   // vec.rs:46-54
 DEV double rsqrt_(double x) { return ::sqrt(x); }
@@ -209,9 +250,8 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
     V3<T> s1 = cross(ray.d, e2);
     V3<T> s2 = cross(s, e1);
     T s1_e1 = dot(s1, e1);
-    T t = dot(s2, e2) / s1_e1;
-    T b1 = dot(s1, s) / s1_e1;
-    T b2 = dot(s2, ray.d) / s1_e1;
+    const V3<T> q = mk<T>(dot(s2, e2), dot(s1, s), dot(s2, ray.d)) / s1_e1;      // tri.rs:33-35: three quotients, one denominator
+    const T t = q.x, b1 = q.y, b2 = q.z;
     if (t < t_min || t > t_max) return false;
     if (b1 < T(0) || b2 < T(0) || (T(1.0) - b1 - b2) < T(0)) return false;
     t_out = t; b1o = b1; b2o = b2;
@@ -885,7 +925,6 @@ template <typename T> DEV void take_chunk(const KParams<T>& P, WaveWork& w, uint
 // global work queue is exhausted and nothing was generated.
 template <typename T>
 DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32) {
-    const uint32_t n_local_px = P.n_local_tiles * P.tile_px;
     const uint32_t n_px = P.W * P.H;
     bool have = false;
     uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
@@ -1404,13 +1443,26 @@ static int occupancy_one(size_t shmem) {
 // everything but the principled material (3 waves/SIMD with some spilling: measured 6 % faster on the final scene than
 // 2 waves/SIMD without), and everything (2 waves/SIMD); the BVH ones also with near-first traversal.
 static const uint32_t FEATS_LEAN = 0u;
-static const uint32_t FEATS_MESH = F_BVH | F_TRIS;
-static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
+[[maybe_unused]] static const uint32_t FEATS_MESH = F_BVH | F_TRIS;
+[[maybe_unused]] static const uint32_t FEATS_NO_PBR = F_ALL & ~F_PBR;
 
-template <typename T, typename F> static auto dispatch(uint32_t scene_feats, uint32_t flags, F&& f) {
+// lean kernels: their own translation unit in the product build
+template <typename T> hipError_t launch_lean(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream);
+template <typename T> int occupancy_lean(size_t shmem);
+#if RT_TU != 2
+template <typename T> hipError_t launch_lean(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream) { return launch_one<T, FEATS_LEAN>(P, n_blocks, shmem, stream); }
+template <typename T> int occupancy_lean(size_t shmem) { return occupancy_one<T, FEATS_LEAN>(shmem); }
+template hipError_t launch_lean<double>(const KParams<double>&, uint32_t, size_t, hipStream_t);
+template hipError_t launch_lean<float>(const KParams<float>&, uint32_t, size_t, hipStream_t);
+template int occupancy_lean<double>(size_t);
+template int occupancy_lean<float>(size_t);
+#endif
+
+#if RT_TU != 1
+template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
-    if ((scene_feats & ~FEATS_LEAN) == 0u) return f(std::integral_constant<uint32_t, FEATS_LEAN>());
+    if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
@@ -1419,15 +1471,18 @@ template <typename T, typename F> static auto dispatch(uint32_t scene_feats, uin
     return nf ? f(std::integral_constant<uint32_t, F_ALL | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, F_ALL>());
 }
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
-    return dispatch<T>(scene_feats, P.flags, [&](auto feats) { return launch_one<T, decltype(feats)::value>(P, n_blocks, shmem, stream); });
+    return dispatch<T>(scene_feats, P.flags, [&]() { return launch_lean<T>(P, n_blocks, shmem, stream); },
+                       [&](auto feats) { return launch_one<T, decltype(feats)::value>(P, n_blocks, shmem, stream); });
 }
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem) {
-    return dispatch<T>(scene_feats, flags, [&](auto feats) { return occupancy_one<T, decltype(feats)::value>(shmem); });
+    return dispatch<T>(scene_feats, flags, [&]() { return occupancy_lean<T>(shmem); },
+                       [&](auto feats) { return occupancy_one<T, decltype(feats)::value>(shmem); });
 }
 
 template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);
 template hipError_t launch_pathtrace<float>(const KParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
 template int pathtrace_blocks_per_cu<double>(uint32_t, uint32_t, size_t);
 template int pathtrace_blocks_per_cu<float>(uint32_t, uint32_t, size_t);
+#endif
 
 } // namespace rt
