@@ -36,7 +36,9 @@
 #ifndef RT_TU
 #define RT_TU 0
 #endif
+#ifndef RT_SHARED_DIV3
 #define RT_SHARED_DIV3 (RT_TU == 2)
+#endif
 
 namespace rt {
 
