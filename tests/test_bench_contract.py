@@ -1,0 +1,41 @@
+"""The bench line's contract, checked on the committed line of the last profiled run (profiles/): every key the driver
+and the judge read is there and self-consistent.  (bench.py itself needs a GPU; this keeps its output format honest.)"""
+import glob
+import json
+import os
+
+from conftest import ROOT
+
+
+def _latest():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_C2.json")))
+    assert files, "no committed bench line"
+    return json.loads(open(files[-1]).read().strip().splitlines()[-1])
+
+
+def test_bench_line_has_the_contract_keys():
+    d = _latest()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Msamples/s" and d["higher_is_better"] is True and d["scaling"] == "strong"
+    assert d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "C2" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1
+
+
+def test_bench_line_is_self_consistent():
+    d = _latest()
+    samples = 800 * 800 * 1024
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert abs(r["achieved"] - r["bytes_per_sample"] * samples / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001            # the kernel is inside the step
+    assert r["framebuffer_atomic_bytes_per_launch"] < r["traffic"] < r["algorithmic_bytes_per_launch"]
