@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstring>
 #include <limits>
+#include <functional>
 #include <map>
+#include <vector>
 #include "rt_scene.h"
 
 namespace rt {
@@ -323,6 +325,20 @@ struct Flattener {
         if (s.world < 0) return fail("world not set");
         Chain c;
         if (!emit(s.world, c, -1)) return false;
+        // which materials' textures read (u, v): ImageTexture, possibly under CheckTextures (texture.rs:45-54)
+        {
+            std::vector<int> uv(f.textures.size(), -1);          // -1 unknown, 0 / 1 known
+            std::function<bool(uint32_t, int)> reads_uv = [&](uint32_t t, int depth) -> bool {
+                if (t >= f.textures.size() || depth > 64) return false;
+                if (uv[t] >= 0) return uv[t] != 0;
+                const auto& tx = f.textures[t];
+                bool r = tx.kind == T_IMAGE || (tx.kind == T_CHECK && (reads_uv(tx.a, depth + 1) || reads_uv(tx.b, depth + 1)));
+                uv[t] = r ? 1 : 0;
+                return r;
+            };
+            for (auto& m : f.materials)
+                if ((m.kind == M_LAMBERTIAN || m.kind == M_DIFFUSE_LIGHT || m.kind == M_ISOTROPIC || m.kind == M_PBR) && reads_uv(m.tex, 0)) m.kind |= MAT_NEEDS_UV;
+        }
         // lights: HittableList of FlipNormal(AARect) / AARect / Sphere (hit.rs:90-96, 125-132; rect.rs:91-111; sphere.rs:104-119);
         // anything else has the trait defaults pdf_value = 0, random = (1,0,0) (hit.rs:29-30)
         for (int l : s.lights) {

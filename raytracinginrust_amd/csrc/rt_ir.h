@@ -24,6 +24,9 @@ namespace rt {
 enum GeomKind : uint32_t { G_RECT = 0, G_SPHERE = 1, G_MSPHERE = 2, G_TRI = 3, G_BVH = 4 };
 enum OpKind : uint32_t { OP_TRANSLATE = 0, OP_ROTATE = 1, OP_FLIP = 2 };
 enum MatKind : uint32_t { M_LAMBERTIAN = 0, M_METAL = 1, M_DIELECTRIC = 2, M_DIFFUSE_LIGHT = 3, M_ISOTROPIC = 4, M_PBR = 5 };
+// DMaterial::kind also carries, above the MatKind byte, whether the material's texture graph reads (u, v) at all (only ImageTexture
+// does, texture.rs:99-120): the hit record's u, v — atan2 + acos per sphere hit — are computed only when something will read them.
+static const uint32_t MAT_KIND_MASK = 0xFFu, MAT_NEEDS_UV = 0x100u;
 enum TexKind : uint32_t { T_CONSTANT = 0, T_CHECK = 1, T_NOISE = 2, T_IMAGE = 3 };
 enum LightKind : uint32_t { L_RECT = 0, L_SPHERE = 1, L_OTHER = 2 };
 

@@ -122,7 +122,7 @@ template <typename T> DEV DTri<T> ld_tri(const DTri<T>* p) { return ld_record(p)
 template <typename T> DEV DOp<T> ld_op(const DOp<T>* p) { DOp<T> r; r.kind = cl(&p->kind); r.axis = cl(&p->axis); r.x = cl(&p->x); r.y = cl(&p->y); r.z = cl(&p->z); return r; }
 DEV DObject ld_obj(const DObject* p) { DObject r; r.geom_kind = cl(&p->geom_kind); r.geom_first = cl(&p->geom_first); r.geom_count = cl(&p->geom_count); r.first_op = cl(&p->first_op); r.n_ops = cl(&p->n_ops); r.medium = cl(&p->medium); r.pad0 = r.pad1 = 0; return r; }
 template <typename T> DEV DBvhNode<T> ld_node(const DBvhNode<T>* p) { return ld_record(p); }
-template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r; r.kind = cl(&p->kind); r.tex = cl(&p->tex); for (int k = 0; k < 3; k++) r.albedo[k] = cl(&p->albedo[k]); r.param = cl(&p->param); return r; }
+template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r; r.kind = cl(&p->kind) & MAT_KIND_MASK; r.tex = cl(&p->tex); for (int k = 0; k < 3; k++) r.albedo[k] = cl(&p->albedo[k]); r.param = cl(&p->param); return r; }
 template <typename T> DEV DPbr<T> ld_pbr(const DPbr<T>* p) { DPbr<T> r; r.metallic = cl(&p->metallic); r.subsurface = cl(&p->subsurface); r.specular = cl(&p->specular); r.roughness = cl(&p->roughness); r.specular_tint = cl(&p->specular_tint); r.anisotropic = cl(&p->anisotropic); r.sheen = cl(&p->sheen); r.sheen_tint = cl(&p->sheen_tint); r.clearcoat = cl(&p->clearcoat); r.clearcoat_gloss = cl(&p->clearcoat_gloss); return r; }
 template <typename T> DEV DTexture<T> ld_tex(const DTexture<T>* p) { DTexture<T> r; r.kind = cl(&p->kind); r.a = cl(&p->a); r.b = cl(&p->b); r.c = cl(&p->c); for (int k = 0; k < 3; k++) r.color[k] = cl(&p->color[k]); r.scale = cl(&p->scale); return r; }
 DEV DLight ld_light(const DLight* p) { DLight r; r.kind = cl(&p->kind); r.index = cl(&p->index); return r; }
@@ -503,6 +503,9 @@ template <typename T> DEV void sphere_uv(V3<T> p, T& u, T& v) {
     v = theta / PI_T;
 }
 
+// (u, v) are read by ImageTexture alone; the flag rides on the material's kind word (rt_ir.h)
+template <typename T> DEV bool mat_reads_uv(const KParams<T>& P, uint32_t mat) { return (cl(&P.materials[mat].kind) & MAT_NEEDS_UV) != 0u; }
+
 // Rebuild the full HitRecord of the winning (object, primitive, t): the same arithmetic the reference runs
 // eagerly inside every `hit`, run once.  Per-lane gathers: lanes may hold different objects.
 template <typename T, uint32_t FEATS>
@@ -522,7 +525,7 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
     if (kind == G_RECT) {                                                             // rect.rs:61-79
         const DRect<T> rc = ld_rect(P.rects + idx);
         uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
-        if ((FEATS & F_TEXTURES) && want_uv) {
+        if ((FEATS & F_TEXTURES) && want_uv && mat_reads_uv(P, rc.mat)) {
             T a = get(r.o, ai) + t * get(r.d, ai);
             T b = get(r.o, bi) + t * get(r.d, bi);
             rec.u = (a - rc.a0) / (rc.a1 - rc.a0);
@@ -539,11 +542,11 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         rec.p = ray_at(r, t);
         V3<T> outward = (rec.p - center) / radius;
         set_face_normal(rec, r.d, outward);
-        if ((FEATS & F_TEXTURES) && want_uv) sphere_uv(outward, rec.u, rec.v);
+        if ((FEATS & F_TEXTURES) && want_uv && mat_reads_uv(P, rec.mat)) sphere_uv(outward, rec.u, rec.v);
     } else if ((FEATS & F_TRIS) && kind == G_TRI) {                                   // tri.rs:42-56
         const DTri<T> tr = ld_tri(P.tris + idx);
         V3<T> e1 = ld3(tr.e1), e2 = ld3(tr.e2);
-        if ((FEATS & F_TEXTURES) && want_uv) {
+        if ((FEATS & F_TEXTURES) && want_uv && mat_reads_uv(P, tr.mat)) {
             V3<T> s = r.o - ld3(tr.v0);
             V3<T> s1 = cross(r.d, e2);
             V3<T> s2 = cross(s, e1);

@@ -1,15 +1,21 @@
-"""Section shares of the kernel from a -DRT_DIAG build (tools only; never a timing source)."""
-import ctypes as C, os, sys, numpy as np
+"""Section shares of the lock-step kernel from a -DRT_DIAG build (tools/mkvariant.sh diag -DRT_DIAG); shares only, never a timing.
+usage: RT_WORKLOADS=C2,C3,C1 python tools/diag_sections.py [spp]"""
+import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/variants/diag.so')
 import torch
-from raytracinginrust_amd import _lib, scenes
-be = _lib.load_path(os.path.join(ROOT, 'raytracinginrust_amd/csrc/variants/diag.so'))
-b, cam, bg = scenes.cornell_box(be)
-W = H = 800; spp = 64
-out = np.zeros((H, W, 3))
-be.lib.rt_render(b.h, C.byref(cam), (C.c_double*3)(*bg), W, H, spp, 50, 0x5EED, 0, out.ctypes.data)
-cyc = (C.c_ulonglong * 6)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
-st = (C.c_ulonglong * 3)(); be.lib.rt_last_stats(b.h, st)
-tot = sum(cyc); names = ['refill', 'flush+init', 'world_hit', 'finalize', 'shade', 'terminate']
-for n, c in zip(names, cyc): print(f'{n:12s} {c/tot*100:6.2f} %   {c/st[1]:9.1f} cycles/iter')
-print('iters', st[1], 'lane util', st[2]/(64*st[1]))
+from PIL import Image
+from raytracinginrust_amd import _lib, render as R, scenes, workloads
+be = _lib.load()
+im = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB'); earth = (im.tobytes(), *im.size)
+spp = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+names = ['refill', 'flush+init', 'world_hit', 'finalize', 'shade', 'terminate']
+for key in os.environ.get('RT_WORKLOADS', 'C2').split(','):
+    w = workloads.WORKLOADS[key]
+    b, cam, bg = workloads.build(w, be, earth)
+    R.render(b, cam, bg, w.W, w.H, min(spp, w.spp), w.max_depth, flags=R.RT_LOCKSTEP_BVH)
+    cyc = (C.c_ulonglong * 6)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
+    st = R.last_stats(b); tot = sum(cyc)
+    print(f'{key} ({w.scene}), {st["wave_iterations"]} wave iterations, alive lanes {st["live_lane_iterations"] / (64 * st["wave_iterations"]):.3f}:')
+    for n, c in zip(names, cyc):
+        print(f'    {n:12s} {c / tot * 100:6.2f} %   {c / st["wave_iterations"]:10.0f} wave-cycles per iteration')
