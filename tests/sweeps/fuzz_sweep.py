@@ -1,7 +1,7 @@
 """One-off wide fuzz: tests/test_fuzz_gpu.py's random scenes for many more seeds (GPU vs CPU oracle, per sample).
-usage: python tools/fuzz_sweep.py [first_seed] [n_seeds]"""
+usage: python tests/sweeps/fuzz_sweep.py [first_seed] [n_seeds]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import torch
 from PIL import Image

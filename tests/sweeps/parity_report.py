@@ -1,7 +1,7 @@
 """Per-scene parity report (GPU vs CPU oracle, per sample) and kernel timings for the four BASELINE scenes; writes PNG
-previews under gpurun_out/.  Developer tool: run on the GPU box with `python tools/parity_report.py`."""
+previews under gpurun_out/.  Developer tool: run on the GPU box with `python tests/sweeps/parity_report.py`."""
 import sys, os, time, numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import torch
 from raytracinginrust_amd import _lib, scenes, render as R
 from oracle import orc
