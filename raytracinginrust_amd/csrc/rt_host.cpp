@@ -72,6 +72,13 @@ static void touch(rt_scene* sc) {
     free_device_scene(sc->s.dev64);
     free_device_scene(sc->s.dev32);
 }
+int rt_scene_set_traversal_schedule(rt_scene* sc, uint32_t start_at, uint32_t stop_below, uint32_t leaf_share64) {
+    if (!sc) return set_err("null argument");
+    if (start_at < 1u || start_at > 64u || stop_below < 1u || stop_below > start_at || leaf_share64 < 1u || leaf_share64 > 64u)
+        return set_err("traversal schedule: need 1 <= stop_below <= start_at <= 64 and 1 <= leaf_share64 <= 64");
+    sc->s.trav_hi = start_at; sc->s.trav_lo = stop_below; sc->s.trav_leaf = leaf_share64;
+    return 0;
+}
 int rt_scene_set_bvh_builder(rt_scene* sc, int mode) {
     if (!sc) return set_err("null argument");
     if (mode != RT_BVH_MEDIAN && mode != RT_BVH_SAH) return set_err("unknown BVH builder");
@@ -425,7 +432,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = effective_flags(f, flags);
     P.tile_px = tile_px; P.rank = rank; P.world = world;
     P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
-    P.trav_hi = 48u; P.trav_lo = 32u; P.trav_leaf = 16u;      // measured best on the teapot room (tools/workloads_time.py sweeps)
+    P.trav_hi = s.trav_hi; P.trav_lo = s.trav_lo; P.trav_leaf = s.trav_leaf;
     if (P.trav_hi < 1u) P.trav_hi = 1u; if (P.trav_hi > 64u) P.trav_hi = 64u;
     if (P.trav_lo < 1u) P.trav_lo = 1u; if (P.trav_lo > P.trav_hi) P.trav_lo = P.trav_hi;
     if (P.trav_leaf < 1u) P.trav_leaf = 1u; if (P.trav_leaf > 64u) P.trav_leaf = 64u;      // >= 1: a box step must win the vote when no leaf is pending

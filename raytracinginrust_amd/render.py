@@ -49,6 +49,13 @@ def set_bvh_builder(b: SceneBuilder, mode: int) -> None:
         raise RenderError(_err(be))
 
 
+def set_traversal_schedule(b: SceneBuilder, start_at: int = 40, stop_below: int = 24, leaf_share64: int = 16) -> None:
+    """Tuning knob of the persistent-traversal loop (scheduling only)."""
+    be = _lib.load()
+    if be.lib.rt_scene_set_traversal_schedule(b.h, start_at, stop_below, leaf_share64) != 0:
+        raise RenderError(_err(be))
+
+
 def prepare(b: SceneBuilder, flags: int = RT_F64) -> None:
     """Flatten, upload and load the kernel now instead of inside the first render (no launch)."""
     be = _lib.load()

@@ -341,6 +341,12 @@ def test_persistent_traversal_on_the_teapot_room(pbe):
     _, pers = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
     assert R.last_traversal_stats(b)["traversal_steps"] > 0
     assert np.array_equal(lock.view(np.uint64), pers.view(np.uint64))
+    # the schedule is a tuning knob: any setting gives the same samples
+    R.set_traversal_schedule(b, 64, 8, 40)
+    _, odd = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    assert np.array_equal(odd.view(np.uint64), pers.view(np.uint64))
+    with pytest.raises(R.RenderError):
+        R.set_traversal_schedule(b, 16, 32, 16)
     # a BVH that is the whole world stays on the lock-step loop unless asked otherwise
     mesh_only = SceneBuilder(pbe)
     lam = mesh_only.Lambertian(mesh_only.ConstantTexture((0.5, 0.5, 0.5)))

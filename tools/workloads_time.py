@@ -12,6 +12,7 @@ for key in os.environ.get('RT_WORKLOADS', 'C1,C2,C3,C4').split(','):
     b, cam, bg = workloads.build(w, be, earth)
     s = min(spp, w.spp)
     if os.environ.get('RT_BVH'): R.set_bvh_builder(b, int(os.environ['RT_BVH']))
+    if os.environ.get('RT_TRAV'): R.set_traversal_schedule(b, *[int(x) for x in os.environ['RT_TRAV'].split(',')])
     flags = int(os.environ.get('RT_FLAGS', '0'))
     for _ in range(2):
         out = R.render(b, cam, bg, w.W, w.H, s, w.max_depth, flags=flags)
