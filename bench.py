@@ -132,10 +132,8 @@ def main():
     w = workloads.WORKLOADS[args.workload]
     earth = None
     if w.scene == "final":
-        from PIL import Image
         from raytracinginrust_amd import scenes
-        im = Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")
-        earth = (im.tobytes(), im.size[0], im.size[1])
+        earth = scenes.load_earthmap()
     b, cam, bg = workloads.build(w, be, earth)
     flags = (R.RT_F32 if args.f32 else R.RT_F64) | (R.RT_NEAR_FIRST_BVH if args.near_first else 0)
     if args.sah:

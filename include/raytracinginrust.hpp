@@ -128,7 +128,9 @@ struct Mesh {                                           // src/mesh.rs
         return Mesh{{s.chk(rt_mesh(s.raw(), p.data(), (uint32_t)positions.size(), indices.data(), (uint32_t)indices.size(), m.id))}};
     }
     // Mesh::load_obj(path, offset, scale, material) -> Result<Mesh, String>, src/mesh.rs:33-61 (throws on failure)
-    static Mesh load_obj(Scene& s, const std::string& path, Vec3 offset, double scale, Material m);
+    static Mesh load_obj(Scene& s, const std::string& path, Vec3 offset, double scale, Material m) {
+        return Mesh{{s.chk(rt_mesh_load_obj(s.raw(), path.c_str(), offset.e, scale, m.id))}};
+    }
 };
 
 struct Camera {                                         // src/camera.rs:19

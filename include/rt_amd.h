@@ -100,6 +100,13 @@ int rt_list_create(rt_scene*);                                                  
 int rt_list_push(rt_scene*, int list, int hittable);                                                   /* HittableList::push, src/hit.rs:52    */
 int rt_mesh(rt_scene*, const double* positions, uint32_t n_positions, const uint32_t* indices,
             uint32_t n_indices, int material);                       /* Mesh::new, src/mesh.rs:16 — returns the `tris` HittableList */
+/* Mesh::load_obj(path, offset, scale, material), src/mesh.rs:33-61: tobj semantics for what the path uses (f32 positions widened,
+ * fan triangulation, models[0] only, then `* scale + offset`); returns the `tris` HittableList; a malformed file is an error
+ * (the reference unwraps tobj's Err, src/main.rs:431).  rt_parse_obj is its parsing step on a buffer: malloc'ed
+ * positions (3 doubles each) and triangle indices, release with rt_free. */
+int rt_mesh_load_obj(rt_scene*, const char* path, const double offset[3], double scale, int material);
+int rt_parse_obj(const char* data, size_t size, const double offset[3], double scale, double** positions_out,
+                 uint32_t* n_positions_out, uint32_t** indices_out, uint32_t* n_indices_out);
 int rt_flip_normal(rt_scene*, int hittable);                                                           /* FlipNormal::new, src/hit.rs:105      */
 int rt_translate(rt_scene*, int hittable, const double offset[3]);                                     /* Translate::new, src/translate.rs:13  */
 int rt_rotate(rt_scene*, int axis, int hittable, double angle_deg);                                    /* Rotate::new, src/rotate.rs:32        */

@@ -43,9 +43,10 @@ def load() -> Backend:
     global _backend
     if _backend is not None:
         return _backend
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("ORC_LIB", LIB_PATH)          # ORC_LIB: the sanitizer build (tests/test_sanitizers.py)
+    if not os.path.exists(path):
         build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     be = Backend(lib, "orc_")
     cam_p = C.POINTER(CameraParams)
     lib.orc_render.restype = C.c_int

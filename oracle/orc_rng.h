@@ -52,7 +52,8 @@ struct Rng {
         if ((r.s[0] | r.s[1] | r.s[2] | r.s[3]) == 0) r.s[0] = 1;
         return r;
     }
-    // host-side streams (scene construction): pixel 0xFFFFFFFF is never a real pixel
+    // host-side streams (scene construction): pixel 0xFFFFFFFF is never a real pixel; its key equals pixel 0x7FFFFFFF's (the factor
+    // 2 drops bit 31), which frames of at most 2^31 - 1 pixels never reach (the product refuses larger frames)
     static inline Rng for_stream(uint64_t seed, uint32_t stream) { return for_path(seed, 0xFFFFFFFFu, stream); }
 
     inline uint32_t next_u32() {

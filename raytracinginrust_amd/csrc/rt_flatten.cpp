@@ -262,10 +262,17 @@ struct Flattener {
                 const HNode& c = s.nodes[h.items[i]];
                 // run of consecutive bare primitives of one kind whose records are contiguous -> one range object
                 if (is_bare_prim(c.kind) && prim_of_node.find(h.items[i]) == prim_of_node.end()) {
+                    // (each item is emitted as the run grows, so a handle pushed twice — `[a, a]`, legal through clone() in the
+                    // reference — ends the run at its second occurrence, which then becomes an object of its own over the one shared
+                    // record; a newly created record always lands at the end of its pool, i.e. at f0 + c0)
                     size_t j = i;
-                    while (j < h.items.size() && s.nodes[h.items[j]].kind == c.kind && prim_of_node.find(h.items[j]) == prim_of_node.end()) j++;
                     uint32_t k0 = 0, f0 = 0, c0 = 0;
-                    for (size_t t = i; t < j; t++) { uint32_t kk, ff, cc; simple_geom(h.items[t], kk, ff, cc); if (t == i) { k0 = kk; f0 = ff; } c0++; }
+                    while (j < h.items.size() && s.nodes[h.items[j]].kind == c.kind && prim_of_node.find(h.items[j]) == prim_of_node.end()) {
+                        uint32_t kk, ff, cc; simple_geom(h.items[j], kk, ff, cc);
+                        if (c0 == 0) { k0 = kk; f0 = ff; }
+                        else if (ff != f0 + c0) return fail("internal: primitive run is not contiguous");
+                        c0++; j++;
+                    }
                     if (medium >= 0 && (emitted_any || j < h.items.size())) return fail("ConstantMedium boundary must flatten to one object");
                     if (!emit_object(k0, f0, c0, chain, medium)) return false;
                     emitted_any = true;

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 #include "../../include/rt_amd.h"
@@ -14,7 +15,10 @@
 
 using namespace rt;
 
-namespace rt { bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height, std::string& err); }
+namespace rt {
+bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rgb, uint32_t& width, uint32_t& height, std::string& err);
+bool parse_obj(const char* data, size_t size, const double offset[3], double scale, std::vector<double>& positions, std::vector<uint32_t>& indices, std::string& err);
+}
 
 struct rt_scene { Scene s; };
 struct rt_rng { Rng r; };
@@ -195,6 +199,37 @@ int rt_mesh(rt_scene* sc, const double* positions, uint32_t n_positions, const u
     }
     return list;
 }
+// tobj::load_obj's part of Mesh::load_obj (src/mesh.rs:40-54): csrc/rt_obj.cpp
+int rt_parse_obj(const char* data, size_t size, const double offset[3], double scale, double** positions_out, uint32_t* n_positions_out,
+                 uint32_t** indices_out, uint32_t* n_indices_out) {
+    if (!data || !offset || !positions_out || !n_positions_out || !indices_out || !n_indices_out) return set_err("null argument");
+    try {
+        std::vector<double> pos; std::vector<uint32_t> idx; std::string err;
+        if (!parse_obj(data, size, offset, scale, pos, idx, err)) return set_err("Failed to load obj file: " + err);
+        double* p = (double*)std::malloc((pos.size() ? pos.size() : 1) * sizeof(double));
+        uint32_t* ix = (uint32_t*)std::malloc((idx.size() ? idx.size() : 1) * sizeof(uint32_t));
+        if (!p || !ix) { std::free(p); std::free(ix); return set_err("out of memory"); }
+        if (!pos.empty()) std::memcpy(p, pos.data(), pos.size() * sizeof(double));
+        if (!idx.empty()) std::memcpy(ix, idx.data(), idx.size() * sizeof(uint32_t));
+        *positions_out = p; *n_positions_out = (uint32_t)(pos.size() / 3); *indices_out = ix; *n_indices_out = (uint32_t)idx.size();
+        return 0;
+    } catch (const std::exception& e) { return set_err(std::string("Failed to load obj file: ") + e.what()); }
+}
+// Mesh::load_obj(path, offset, scale, material), src/mesh.rs:33-61 -> the `tris` HittableList (like rt_mesh)
+int rt_mesh_load_obj(rt_scene* sc, const char* path, const double offset[3], double scale, int mat) {
+    if (!sc || !path || !offset) return set_err("null argument");
+    if (!mat_ok(sc, mat)) return scene_err(sc, "Mesh: bad material handle");
+    try {
+        FILE* f = std::fopen(path, "rb");
+        if (!f) return scene_err(sc, std::string("Failed to load obj file: cannot open ") + path);
+        std::string data; char buf[1 << 16]; size_t n;
+        while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) data.append(buf, n);
+        std::fclose(f);
+        std::vector<double> pos; std::vector<uint32_t> idx; std::string err;
+        if (!parse_obj(data.data(), data.size(), offset, scale, pos, idx, err)) return scene_err(sc, "Failed to load obj file: " + err);
+        return rt_mesh(sc, pos.data(), (uint32_t)(pos.size() / 3), idx.data(), (uint32_t)idx.size(), mat);
+    } catch (const std::exception& e) { return scene_err(sc, std::string("Failed to load obj file: ") + e.what()); }
+}
 int rt_flip_normal(rt_scene* sc, int h) {
     if (!node_ok(sc, h)) return scene_err(sc, "FlipNormal: bad hittable handle");
     HNode n; n.kind = HNode::FLIP; n.child = h; return add_node(sc, n);
@@ -265,13 +300,15 @@ int rt_write_ppm(const char* path, const double* rgb_sum, uint32_t W, uint32_t H
 // image::open(path).to_rgb8() for the reference's asset class (src/main.rs:248,491): baseline JPEG -> RGB8 (csrc/rt_jpeg.cpp)
 uint8_t* rt_decode_jpeg_rgb8(const uint8_t* data, size_t size, uint32_t* width, uint32_t* height) {
     if (!data || !width || !height) { set_err("null argument"); return nullptr; }
-    std::vector<uint8_t> rgb; std::string err; uint32_t w = 0, h = 0;
-    if (!decode_jpeg_rgb8(data, size, rgb, w, h, err)) { set_err("image not found / not decodable: " + err); return nullptr; }
-    uint8_t* out = (uint8_t*)std::malloc(rgb.size());
-    if (!out) { set_err("out of memory"); return nullptr; }
-    std::memcpy(out, rgb.data(), rgb.size());
-    *width = w; *height = h;
-    return out;
+    try {                                                               // no C++ exception may cross the C boundary
+        std::vector<uint8_t> rgb; std::string err; uint32_t w = 0, h = 0;
+        if (!decode_jpeg_rgb8(data, size, rgb, w, h, err)) { set_err("image not found / not decodable: " + err); return nullptr; }
+        uint8_t* out = (uint8_t*)std::malloc(rgb.size());
+        if (!out) { set_err("out of memory"); return nullptr; }
+        std::memcpy(out, rgb.data(), rgb.size());
+        *width = w; *height = h;
+        return out;
+    } catch (const std::exception& e) { set_err(std::string("image not decodable: ") + e.what()); return nullptr; }
 }
 void rt_free(void* p) { std::free(p); }
 
@@ -485,6 +522,7 @@ int check_frame_args(rt_scene* sc, const rt_camera* cam, const double* bg, uint3
     if (!sc || !cam || !bg) return set_err("null argument");
     if (W < 2 || H < 2) return set_err("W and H must be >= 2 (u,v divide by W-1 and H-1, src/main.rs:817-818)");
     if (spp == 0) return set_err("samples_per_pixel must be >= 1");
+    if ((uint64_t)W * H > 0x7FFFFFFFull) return set_err("frame too large: W*H must be <= 2^31 - 1 (per-path RNG keys, csrc/rt_rng.h)");
     return 0;
 }
 

@@ -73,12 +73,16 @@ inline int decode_symbol(BitReader& br, const Huff& h, bool& ok) {
 }
 inline int extend(int v, int t) { return (t == 0) ? 0 : (v < (1 << (t - 1)) ? v - (1 << t) + 1 : v); }
 
-inline int f2f(double x) { return (int)(x * 4096 + 0.5); }
-inline int fsh(int x) { return x * 4096; }
-inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+// The IDCT runs in 64-bit integers: for every legal 8-bit stream the values are those of the 32-bit original, and a
+// hostile stream (DC predictors run up to the cap below, 15-bit AC magnitudes times 8-bit quantisers: |coef| < 2^24,
+// pass 1 < 2^41, pass 2 < 2^48) cannot overflow.
+typedef long long idct_t;
+inline idct_t f2f(double x) { return (idct_t)(x * 4096 + 0.5); }
+inline idct_t fsh(idct_t x) { return x * 4096; }
+inline uint8_t clamp8(idct_t x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
 
 #define IDCT_1D(s0, s1, s2, s3, s4, s5, s6, s7)                                               \
-    int t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                   \
+    idct_t t0, t1, t2, t3, p1, p2, p3, p4, p5, x0, x1, x2, x3;                                 \
     p2 = s2; p3 = s6;                                                                         \
     p1 = (p2 + p3) * f2f(0.5411961);                                                          \
     t2 = p1 + p3 * (-f2f(1.847759065));                                                       \
@@ -95,11 +99,11 @@ inline uint8_t clamp8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x))
     t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
 
 void idct_block(const int* coef /* natural order, dequantised */, uint8_t* out, int stride) {
-    int val[64];
+    idct_t val[64];
     for (int i = 0; i < 8; i++) {                       // columns
-        const int* d = coef + i; int* v = val + i;
+        const int* d = coef + i; idct_t* v = val + i;
         if (d[8] == 0 && d[16] == 0 && d[24] == 0 && d[32] == 0 && d[40] == 0 && d[48] == 0 && d[56] == 0) {
-            int dc = d[0] * 4;
+            idct_t dc = (idct_t)d[0] * 4;
             v[0] = v[8] = v[16] = v[24] = v[32] = v[40] = v[48] = v[56] = dc;
         } else {
             IDCT_1D(d[0], d[8], d[16], d[24], d[32], d[40], d[48], d[56])
@@ -111,7 +115,7 @@ void idct_block(const int* coef /* natural order, dequantised */, uint8_t* out, 
         }
     }
     for (int i = 0; i < 8; i++) {                       // rows
-        const int* v = val + i * 8; uint8_t* o = out + i * stride;
+        const idct_t* v = val + i * 8; uint8_t* o = out + i * stride;
         IDCT_1D(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7])
         x0 += 65536 + (128 << 17); x1 += 65536 + (128 << 17); x2 += 65536 + (128 << 17); x3 += 65536 + (128 << 17);
         o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17);
@@ -120,6 +124,8 @@ void idct_block(const int* coef /* natural order, dequantised */, uint8_t* out, 
         o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
     }
 }
+
+const uint64_t MAX_PIXELS = 64ull << 20;      // the header's 16-bit dimensions alone would allow 4 Gpixel allocations
 
 inline int cfix(double x) { return (int)(x * (double)(1 << 20) + 0.5); }
 inline uint8_t clamp_fixed(int v) { int r = v >> 20; return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r)); }
@@ -138,7 +144,8 @@ bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rg
     size_t i = 2;
     while (i + 4 <= size) {
         if (data[i] != 0xFF) return fail("corrupt JPEG: marker expected");
-        while (i < size && data[i] == 0xFF && i + 1 < size && data[i + 1] == 0xFF) i++;       // fill bytes
+        while (i + 1 < size && data[i + 1] == 0xFF) i++;       // fill bytes
+        if (i + 2 > size) return fail("truncated JPEG");
         uint8_t m = data[i + 1];
         i += 2;
         if (m == 0xD8 || (m >= 0xD0 && m <= 0xD7) || m == 0x01) continue;
@@ -152,8 +159,9 @@ bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rg
             while (k < n) {
                 int pq = seg[k] >> 4, tq = seg[k] & 15; k++;
                 if (tq > 3) return fail("bad quantisation table id");
-                if (k + (pq ? 128 : 64) > n) return fail("truncated DQT");
-                for (int z = 0; z < 64; z++) { qt[tq][z] = pq ? (uint16_t)((seg[k] << 8) | seg[k + 1]) : seg[k]; k += pq ? 2 : 1; }
+                if (pq != 0) return fail("only 8-bit quantisation tables are supported (baseline JPEG)");
+                if (k + 64 > n) return fail("truncated DQT");
+                for (int z = 0; z < 64; z++) qt[tq][z] = seg[k++];
                 qt_ok[tq] = true;
             }
         } else if (m == 0xC4) {                                             // DHT
@@ -175,6 +183,7 @@ bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rg
             ncomp = seg[5];
             if (ncomp != 1 && ncomp != 3) return fail("only grey or YCbCr JPEG is supported");
             if (n < 6 + (size_t)ncomp * 3 || width == 0 || height == 0) return fail("bad SOF");
+            if ((uint64_t)width * height > MAX_PIXELS) return fail("JPEG frame larger than 64 Mpixel");
             for (int c = 0; c < ncomp; c++) {
                 comp[c].id = seg[6 + c * 3]; comp[c].h = seg[7 + c * 3] >> 4; comp[c].v = seg[7 + c * 3] & 15; comp[c].tq = seg[8 + c * 3];
                 if (comp[c].h != 1 || comp[c].v != 1) return fail("subsampled JPEG components are not supported (only 1x1 sampling)");
@@ -217,6 +226,7 @@ bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rg
                     if (!ok || t > 11) return fail("corrupt JPEG entropy data (DC)");
                     int diff = extend(br.bits(t), t);
                     comp[c].pred += diff;
+                    if (comp[c].pred < -65536 || comp[c].pred > 65535) return fail("corrupt JPEG entropy data (DC out of range)");
                     coef[0] = comp[c].pred * qt[comp[c].tq][0];
                     for (int k = 1; k < 64;) {
                         int rs = decode_symbol(br, hac[comp[c].ta], ok);

@@ -9,7 +9,10 @@
 //              no integer multiplies on the per-draw path, which are quarter-rate on CDNA)
 //   keying     id = (pixel << 32) | sample; z = seed + 2*id*G (G = 0x9E3779B97F4A7C15);
 //              (s0,s1) = lo/hi of mix64(z + G), (s2,s3) = lo/hi of mix64(z + 2G)   [SplitMix64 finaliser]
-//              pixel = output-order pixel index (row 0 = top); pixel 0xFFFFFFFF = host streams
+//              pixel = output-order pixel index (row 0 = top); pixel 0xFFFFFFFF = host streams.
+//              The factor 2 shifts bit 31 of `pixel` out of the 64-bit word, so pixels p and p + 2^31 share a stream and the
+//              host streams' key equals that of pixel 0x7FFFFFFF: frames are therefore limited to W*H <= 0x7FFFFFFF pixels
+//              (indices <= 0x7FFFFFFE; rt_render* refuse larger frames), which keeps every path key and the host key distinct.
 //   next_u64   (next_u32 << 32) | next_u32
 //   U01        rng.gen::<f64>()      = (next_u64 >> 11) * 2^-53
 //   R(a,b)     rng.gen_range(a..b)   = (bits(0x3FF<<52 | next_u64 >> 12) - 1.0) * (b - a) + a,

@@ -18,28 +18,6 @@
 
 using namespace rtr;
 
-// Mesh::load_obj, src/mesh.rs:33-61, with tobj 3.2.3 semantics for what the path uses: positions parsed as f32 and
-// widened (mesh.rs:51), faces fan-triangulated, models[0] only (mesh.rs:42), then `* scale + offset`.
-Mesh Mesh::load_obj(Scene& s, const std::string& path, Vec3 offset, double scale, Material m) {
-    std::ifstream f(path);
-    if (!f) throw Error("Failed to load obj file: " + path);
-    std::vector<Vec3> pos; std::vector<uint32_t> idx; bool have_faces = false; std::string line;
-    while (std::getline(f, line)) {
-        std::istringstream is(line); std::string tag; is >> tag;
-        if (tag == "v") {
-            std::string a, b, c; is >> a >> b >> c;
-            double x = (double)std::strtof(a.c_str(), nullptr), y = (double)std::strtof(b.c_str(), nullptr), z = (double)std::strtof(c.c_str(), nullptr);
-            pos.push_back(Vec3(x * scale + offset.x(), y * scale + offset.y(), z * scale + offset.z()));
-        } else if (tag == "f") {
-            have_faces = true;
-            std::vector<uint32_t> vs; std::string tok;
-            while (is >> tok) { long k = std::strtol(tok.c_str(), nullptr, 10); vs.push_back((uint32_t)(k > 0 ? k - 1 : (long)pos.size() + k)); }
-            for (size_t k = 1; k + 1 < vs.size(); k++) { idx.push_back(vs[0]); idx.push_back(vs[k]); idx.push_back(vs[k + 1]); }
-        } else if ((tag == "o" || tag == "g") && have_faces) break;
-    }
-    return Mesh::new_(s, pos, idx, m);
-}
-
 static const uint32_t STREAM_RANDOM_SCENE = 0, STREAM_FINAL_SCENE = 1, STREAM_TWO_PERLIN = 2;
 
 // src/main.rs:212-227

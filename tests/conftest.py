@@ -28,11 +28,10 @@ def pbe():
 
 @pytest.fixture(scope="session")
 def earth():
-    """Decoded earthmap texels (tests/golden/earthmap_256x128.png) -> (bytes, w, h)."""
-    from PIL import Image
+    """The reference's own 1024x512 earth texture (tests/golden/earthmap.jpg = its earthmap.jpg, src/main.rs:491-495), decoded by
+    the library's JPEG ingest -> (bytes, w, h)."""
     from raytracinginrust_amd import scenes
-    im = Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")
-    return im.tobytes(), im.size[0], im.size[1]
+    return scenes.load_earthmap()
 
 
 def build_scene(name, backend, earth=None):

@@ -3,7 +3,8 @@ container where /root/reference is mounted; the GPU box only sees the committed 
 
   teapot.obj            byte copy of /root/reference/teapot.obj (Utah teapot mesh: 530 v, 1024 f) — input data
                         for BASELINE config 4 (tri.rs / mesh.rs path)
-  earthmap_256x128.png  /root/reference/earthmap.jpg (1024x512 baseline JPEG) decoded with Pillow and box-
+  earthmap.jpg          byte copy of /root/reference/earthmap.jpg — the texture BASELINE config 3 (final scene) and `earth` load
+  earthmap_256x128.png  (small fixture for the JPEG-decoder tests only) /root/reference/earthmap.jpg (1024x512 baseline JPEG) decoded with Pillow and box-
                         downsampled 4x, stored losslessly — input texels for the ImageTexture path.  (The
                         reference decodes with the `image` crate; decoders may differ by +-1 LSB, SURVEY §8(c),
                         so the decoded texels, not the JPEG, are the fixture.)
@@ -12,6 +13,9 @@ import os, shutil
 from PIL import Image
 here = os.path.dirname(os.path.abspath(__file__))
 shutil.copyfile("/root/reference/teapot.obj", os.path.join(here, "teapot.obj"))
+# earthmap.jpg: byte copy of the reference's texture asset (1024x512 baseline 4:4:4 JPEG, loaded at src/main.rs:248,491-495) — the
+# input data of BASELINE config 3; decoded at run time by the library's own JPEG ingest (csrc/rt_jpeg.cpp)
+shutil.copyfile("/root/reference/earthmap.jpg", os.path.join(here, "earthmap.jpg"))
 im = Image.open("/root/reference/earthmap.jpg").convert("RGB")
 assert im.size == (1024, 512)
 im.resize((256, 128), Image.BOX).save(os.path.join(here, "earthmap_256x128.png"), optimize=True)

@@ -12,7 +12,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, os.path.dirname(HERE))
 from conftest import build_scene  # noqa: E402
 from oracle import orc  # noqa: E402
-from PIL import Image  # noqa: E402
 from raytracinginrust_amd import scenes  # noqa: E402
 
 CASES = {  # name: (W, H, spp, depth)
@@ -23,8 +22,7 @@ CASES = {  # name: (W, H, spp, depth)
 }
 
 if __name__ == "__main__":
-    im = Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")
-    earth = (im.tobytes(), im.size[0], im.size[1])
+    earth = scenes.load_earthmap()          # the reference's own 1024x512 texture, decoded by the library's JPEG ingest
     be = orc.load()
     for name, (W, H, spp, depth) in CASES.items():
         b, cam, bg = build_scene(name, be, earth)

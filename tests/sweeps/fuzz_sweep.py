@@ -9,7 +9,7 @@ from oracle import orc
 from raytracinginrust_amd import _lib, render as R, scenes
 from test_fuzz_gpu import _rand_scene, SAMPLE_RTOL
 pbe, obe = _lib.load(), orc.load()
-im = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB'); earth = (im.tobytes(), *im.size)
+earth = scenes.load_earthmap()
 first, n = int(sys.argv[1]) if len(sys.argv) > 1 else 100, int(sys.argv[2]) if len(sys.argv) > 2 else 200
 W = H = 40; spp, depth = 8, 12
 worst = 0.0; n_bad_total = 0; n_samples = 0; failures = []

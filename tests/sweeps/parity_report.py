@@ -7,7 +7,7 @@ from raytracinginrust_amd import _lib, scenes, render as R
 from oracle import orc
 from PIL import Image
 obe = orc.load(); be = _lib.load()
-earth = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB'); ew, eh = earth.size; eb = earth.tobytes()
+eb, ew, eh = scenes.load_earthmap()
 def build(name, backend):
     if name == 'cornell': return scenes.cornell_box(backend)
     if name == 'random': return scenes.random_scene(backend, aspect_ratio=16/9)

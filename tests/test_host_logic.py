@@ -95,6 +95,27 @@ def test_flatten_tables(pbe, earth):
     assert t["triangles"] == 1024 and t["bvh_nodes"] == 2047 and t["rects"] == 6
 
 
+def test_flatten_duplicated_handle_in_a_list(pbe):
+    """`list.push(a.clone()); list.push(a)` is legal in the reference: the second occurrence must not stretch the first one's
+    primitive range over a neighbouring (or the padding) record."""
+    b = SceneBuilder(pbe)
+    m = b.Lambertian(b.ConstantTexture((1, 1, 1)))
+    a, c = b.Sphere((0, 0, 0), 1.0, m), b.Sphere((5, 0, 0), 1.0, m)
+    inner = b.HittableList(); inner.push(a); inner.push(a)
+    world = b.HittableList(); world.push(inner); world.push(c)
+    b.set_scene(world, [])
+    f = R.flatten(b)
+    assert f["spheres"] == 2                  # a's record is shared
+    assert f["objects"] == 3                  # [a], [a] again, [c]: no range covers a record it does not own
+    # the same list without the duplicate merges into one run
+    b2 = SceneBuilder(pbe)
+    m2 = b2.Lambertian(b2.ConstantTexture((1, 1, 1)))
+    w2 = b2.HittableList(); w2.push(b2.Sphere((0, 0, 0), 1.0, m2)); w2.push(b2.Sphere((5, 0, 0), 1.0, m2))
+    b2.set_scene(w2, [])
+    f2 = R.flatten(b2)
+    assert (f2["spheres"], f2["objects"]) == (2, 1)
+
+
 def test_sah_builder_keeps_the_table_shapes(pbe, earth):
     """The opt-in SAH builder only reshapes the tree: same leaves, same node count (one object per leaf), within the depth limit."""
     for name in ("random", "final", "teapot"):
@@ -187,6 +208,17 @@ def test_jpeg_ingest_matches_an_independent_decoder():
     # and the decoded JPEG is the texture the PNG fixture holds, up to JPEG loss
     png = np.asarray(Image.open(scenes.asset_path("earthmap_256x128.png")).convert("RGB")).astype(int)
     assert np.abs(ours - png.mean(axis=2, keepdims=True)).mean() < 12      # grey JPEG vs the colour fixture's luma-ish mean
+
+
+def test_jpeg_ingest_of_the_reference_asset_matches_an_independent_decoder():
+    """The reference's earthmap.jpg itself (1024x512, baseline, 4:4:4; src/main.rs:491-495) through csrc/rt_jpeg.cpp vs Pillow."""
+    from PIL import Image
+    data, w, h = scenes.load_earthmap()
+    ours = np.frombuffer(data, dtype=np.uint8).reshape(h, w, 3).astype(int)
+    ref = np.asarray(Image.open(scenes.asset_path("earthmap.jpg")).convert("RGB")).astype(int)
+    assert ours.shape == ref.shape == (512, 1024, 3)
+    d = np.abs(ours - ref)
+    assert d.max() <= 3 and d.mean() < 0.01 and (d.max(axis=2) == 0).mean() > 0.995
 
 
 def test_jpeg_ingest_rejects_what_it_does_not_support(tmp_path):

@@ -20,9 +20,7 @@ def build(be):
     if a.scene == 'random': return scenes.random_scene(be, aspect_ratio=1.0)
     if a.scene == 'teapot': return scenes.cornell_test(be, scenes.asset_path('teapot.obj'))
     if a.scene == 'final':
-        from PIL import Image
-        im = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB')
-        return scenes.final_scene(be, im.tobytes(), im.size[0], im.size[1])
+        return scenes.final_scene(be, *scenes.load_earthmap())
 
 variants = []
 for spec in a.libs:

@@ -6,7 +6,7 @@ import numpy as np, torch
 from PIL import Image
 from raytracinginrust_amd import _lib, render as R, scenes
 be = _lib.load()
-earth = scenes.load_image_rgb8(scenes.asset_path('earthmap_256x128_444.jpg'))
+earth = scenes.load_earthmap()
 out_dir = os.path.join(ROOT, 'gpurun_out', 'previews'); os.makedirs(out_dir, exist_ok=True)
 jobs = [('cornell_box', scenes.cornell_box(be), 256, 256, 1024, 50), ('random_scene', scenes.random_scene(be, aspect_ratio=16 / 9), 384, 216, 256, 8),
         ('final_scene', scenes.final_scene(be, *earth), 256, 256, 1024, 50), ('cornell_test_teapot', scenes.cornell_test(be, scenes.asset_path('teapot.obj'), aspect_ratio=16 / 9), 384, 216, 512, 50)]

@@ -5,7 +5,7 @@ import torch
 from PIL import Image
 from raytracinginrust_amd import _lib, render as R, scenes, workloads
 be = _lib.load()
-im = Image.open(scenes.asset_path('earthmap_256x128.png')).convert('RGB'); earth = (im.tobytes(), *im.size)
+earth = scenes.load_earthmap()
 spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 for key in os.environ.get('RT_WORKLOADS', 'C1,C2,C3,C4').split(','):
     w = workloads.WORKLOADS[key]
