@@ -7,10 +7,20 @@
 A "step" is one whole frame: every rank renders its interleaved tiles (one persistent HIP kernel launch per
 rank), then ONE gather (RCCL over xGMI) moves them to rank 0.  The frame is fixed as N grows (strong scaling).
 For N > 1 launch with `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`.
-Rank 0 prints one JSON line.  `roofline.achieved` = algorithmic bytes per launch (SURVEY §8(d) model x samples in
-the launch) / mean kernel duration from HIP events recorded on the launch stream inside the timed region.
-`cpu_baseline` (N = 1 only) times the CPU oracle — a restatement of the reference, not the Rust binary, which
-cannot be built here — on a bounded sample of the same workload.
+Rank 0 prints one JSON line.
+
+`roofline` (BASELINE's metric: "% HBM roofline"): `achieved` = ALGORITHMIC bytes per launch (SURVEY §8(d) event x record-size
+model: the committed per-workload constant of raytracinginrust_amd/workloads.py x the samples in rank 0's launch) / mean kernel
+duration from HIP events recorded on the launch stream inside the timed region; `peak` = 8 TB/s.  The scene is L2/LDS-resident, so
+this is a model figure, not HBM utilisation: physical traffic (`traffic`) and what really bounds the kernel — f64 VALU issue,
+`valu_roofline` — come from the committed rocprofv3 --pmc passes of this same command and are used only when that profile was
+taken on THIS build of the kernels (matching `kernel_source_id`); otherwise they are null.
+
+`workloads`: the other BASELINE configs (C1, C3, C4, C5) timed the same way, one reduced-spp warm-up frame + one full frame each,
+so that every config's Msamples/s and roofline fraction is on the driver's clock.
+
+`cpu_baseline` (N = 1 only): the CPU oracle — a restatement of the reference, not the Rust binary, which cannot be built here —
+on a bounded sample of the same workload, in both threading shapes BASELINE.md names, counters compiled out.
 """
 import argparse
 import json
@@ -22,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD = 1024               # 256 CUs x 4 SIMDs
 
 
 def usable_cores():
@@ -45,46 +56,102 @@ def usable_cores():
 
 
 def cpu_baseline(w, sample_spp, earth=None):
-    """CPU restatement of the reference (oracle/), all host threads, on the workload's own pixel grid.  `sample_spp` > 0 fixes
-    the samples per pixel of the bounded sample; -1 sizes it for about 8 s of wall time from a 1-spp calibration pass.
-    Also returns the oracle's algorithmic bytes/sample for this workload."""
+    """CPU restatement of the reference (oracle/, built with its event counters compiled out), all usable host threads, on the
+    workload's own pixel grid, in the two threading shapes BASELINE.md §2 names:
+      rows              threads over image rows (dynamic)                         -> `value`
+      reference_shaped  pixels sequential, the samples of ONE pixel split over the threads, as the reference's
+                        `(0..SPP).into_par_iter()` does (src/main.rs:811), persistent worker pool
+    `sample_spp` > 0 fixes the samples per pixel of the `rows` sample; -1 sizes it for about 8 s of wall time from a 1-spp
+    calibration pass.  The reference-shaped sample is a band of rows in the middle of the frame at the workload's full spp, sized
+    for about 4 s."""
     from oracle import orc
     from raytracinginrust_amd import workloads
-    be = orc.load()
+    be = orc.load_nocount()
     b, cam, bg = workloads.build(w, be, earth)
     threads = usable_cores()
+    t = time.perf_counter()
+    orc.render(b, cam, bg, w.W, w.H, 1, w.max_depth, nthreads=threads, mode=0)
+    per_spp = max(time.perf_counter() - t, 1e-3)
     if sample_spp < 0:
-        t = time.perf_counter()
-        orc.render(b, cam, bg, w.W, w.H, 1, w.max_depth, nthreads=threads, mode=0)
-        per_spp = max(time.perf_counter() - t, 1e-3)
         sample_spp = int(min(256, max(4, round(8.0 / per_spp))))
     t = time.perf_counter()
-    _, cnt = orc.render(b, cam, bg, w.W, w.H, sample_spp, w.max_depth, want_counters=True, nthreads=threads, mode=0)
+    orc.render(b, cam, bg, w.W, w.H, sample_spp, w.max_depth, nthreads=threads, mode=0)
     dt = time.perf_counter() - t
     n = w.W * w.H * sample_spp
+    # reference-shaped: rows [r0, r1) around the middle of the frame at full spp, about 4 s of work at the rate just measured
+    rate = n / dt
+    band = int(max(1, min(w.H, round(4.0 * rate / (w.W * w.spp)))))
+    r0 = max(0, w.H // 2 - band // 2)
+    t = time.perf_counter()
+    orc.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth, nthreads=threads, mode=1, rows=(r0, r0 + band))
+    dt1 = time.perf_counter() - t
+    n1 = band * w.W * w.spp
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": threads, "kind": "port",
-            "sample": f"{w.scene} {w.W}x{w.H} at {sample_spp} spp ({n / 1e6:.1f} Msamples, {dt:.1f} s wall, "
-                      f"oracle f64, threads over rows)"}, orc.algorithmic_bytes_per_sample(cnt, sample_spp)
+            "sample": f"{w.scene} {w.W}x{w.H} at {sample_spp} spp ({n / 1e6:.1f} Msamples, {dt:.1f} s wall, oracle f64, threads over rows)",
+            "reference_shaped": {"value": n1 / dt1 / 1e6, "unit": "Msamples/s", "cores": threads,
+                                 "sample": f"{w.scene} {w.W}x{w.H}, rows {r0}..{r0 + band} at the full {w.spp} spp ({n1 / 1e6:.1f} Msamples, "
+                                           f"{dt1:.1f} s wall), pixels sequential, each pixel's samples split over the threads (src/main.rs:811)"},
+            "compiler": orc.BUILD_INFO["compiler"], "flags": orc.BUILD_INFO["flags"],
+            "note": "CPU restatement of the reference (oracle/), never the Rust binary; event counters compiled out"}
 
 
-def pmc_traffic_bytes(workload_key):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE and
-    WRITE_SIZE runs; counters are in KB; raw values — the accesses are 8-byte f64 atomics, for which the guide has no
-    correction).  None if no profile of this workload is committed."""
+def pmc_profile(workload_key):
+    """Per-dispatch counter means from the committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE /
+    WRITE_SIZE / SQ passes, tools/profile_pmc.sh), newest snapshot of this workload — used ONLY when it was taken on this
+    build of the kernels (the summary's kernel_source_id equals the hash of the kernel sources in this tree).  Returns
+    (values, file name) or (None, reason)."""
     import csv
     import glob
+    from raytracinginrust_amd import buildinfo
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_bench_{workload_key}_pmc_summary.csv")))
     if not files:
-        return None, None, None
-    vals = {r["counter"]: float(r["mean_per_dispatch"]) for r in csv.DictReader(open(files[-1]))}
-    if "FETCH_SIZE" not in vals or "WRITE_SIZE" not in vals:
-        return None, None, None
-    # secondary figure (SURVEY 8(d)): fraction of SIMD time the vector ALU is busy.  SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES
-    # both count quad-cycles summed over waves; SQ_WAVES / 1024 SIMDs = resident waves per SIMD of the persistent grid.
+        return None, "no PMC profile of this workload committed"
+    rows = list(csv.DictReader(open(files[-1])))
+    ident = [r["mean_per_dispatch"] for r in rows if r["counter"] == "kernel_source_id"]
+    if not ident or ident[0] != buildinfo.kernel_source_id():
+        return None, f"{os.path.basename(files[-1])} was taken on another build of the kernels (not used)"
+    vals = {r["counter"]: float(r["mean_per_dispatch"]) for r in rows if r["counter"] != "kernel_source_id"}
+    return vals, os.path.basename(files[-1])
+
+
+def roofline_of(w, bps, local_samples, k_ms, n_flush, kernel_name, with_pmc):
+    achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, KB counters x 1024; raw values)",
+            "traffic_source": None,
+            "algorithmic_bytes_per_launch": bps * local_samples, "bytes_per_sample": bps,
+            "bytes_per_sample_source": "raytracinginrust_amd/workloads.py BYTES_PER_SAMPLE (oracle event counters, tests/sweeps/measure_bytes_per_sample.py)",
+            "kernel": kernel_name, "kernel_ms": k_ms,
+            "framebuffer_atomics_per_launch": 3 * n_flush,       # what the kernel itself counted in THIS run: f64 atomic adds, 8 B each
+            "framebuffer_atomic_bytes_per_launch": 24 * n_flush,
+            "note": "model figure: algorithmic bytes (event x record-size, SURVEY 8(d)) over the HBM peak, as BASELINE's metric asks; the "
+                    "scene is L2/LDS-resident and the kernel is bound by f64 VALU issue (valu_roofline), not by HBM"}
     valu = None
-    if all(k in vals for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES")) and vals["SQ_WAVE_CYCLES"] > 0:
-        valu = vals["SQ_ACTIVE_INST_VALU"] * (vals["SQ_WAVES"] / 1024.0) / vals["SQ_WAVE_CYCLES"]
-    return (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0, os.path.basename(files[-1]), valu
+    if with_pmc:
+        vals, src = pmc_profile(w.key)
+        if vals is None:
+            roof["traffic_source"] = src
+        else:
+            if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+                roof["traffic"] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                roof["traffic_source"] = f"profiles/{src}: committed rocprofv3 --pmc passes of this command on this build (not measured in this run)"
+            need = ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU")
+            if all(k in vals for k in need) and vals["SQ_WAVE_CYCLES"] > 0 and vals["SQ_ACTIVE_INST_VALU"] > 0:
+                # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over waves; the grid is persistent, so
+                # SQ_WAVE_CYCLES / SQ_WAVES is the launch's length in quad-cycles and SQ_WAVES / 1024 the waves per SIMD.
+                busy = vals["SQ_ACTIVE_INST_VALU"] * (vals["SQ_WAVES"] / N_SIMD) / vals["SQ_WAVE_CYCLES"]
+                lanes = vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"])
+                valu = {"bound": "f64 VALU issue", "valu_busy_frac": busy, "valu_lane_utilisation": lanes, "frac": busy * lanes,
+                        "frac_meaning": "useful VALU lane-slots / VALU lane-slots the SIMDs could have issued over the launch",
+                        "source": f"profiles/{src}: committed rocprofv3 --pmc passes of this command on this build (not measured in this run)"}
+    return roof, valu
+
+
+def kernel_name_of(w, f32):
+    t = "float" if f32 else "double"
+    feats = {"cornell": "0 (lean: rects + instances + Lambertian/Metal/DiffuseLight)", "random": "the sphere-BVH instantiation",
+             "final": "the all-features-but-PBR instantiation", "teapot": "BVH|TRIS|PERSIST (mesh, persistent traversal)"}[w.scene]
+    return f"rt::pathtrace_kernel<{t}, FEATS>, FEATS = {feats}"
 
 
 def main():
@@ -93,6 +160,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C2")
+    ap.add_argument("--also", default="C1,C3,C4,C5",
+                    help="other BASELINE configs to time after the main one (one reduced-spp warm-up frame + one full frame each); 'none' to skip")
     ap.add_argument("--tile-px", type=int, default=67, help="pixels per tile; prime by default (see dist.DEFAULT_TILE_PX)")
     ap.add_argument("--f32", action="store_true", help="throughput variant (not the headline: reduced precision)")
     ap.add_argument("--near-first", action="store_true", help="opt-in RT_NEAR_FIRST_BVH traversal (not the reference's order)")
@@ -129,17 +198,10 @@ def main():
             dist.init_process_group(backend)
 
     be = _lib.load()            # after `import torch`: one HIP runtime in the process
-    w = workloads.WORKLOADS[args.workload]
+    from raytracinginrust_amd import scenes
     earth = None
-    if w.scene == "final":
-        from raytracinginrust_amd import scenes
-        earth = scenes.load_earthmap()
-    b, cam, bg = workloads.build(w, be, earth)
     flags = (R.RT_F32 if args.f32 else R.RT_F64) | (R.RT_NEAR_FIRST_BVH if args.near_first else 0)
-    if args.sah:
-        R.set_bvh_builder(b, R.RT_BVH_SAH)
-    tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world,
-                        pipeline=args.pipeline)
+    cdev = "cuda" if backend == "nccl" else "cpu"
 
     def sync():
         torch.cuda.synchronize()            # every stream of this rank (frames run on two alternating side streams)
@@ -147,70 +209,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one-time initialisation (scene flatten + upload, code-object load, event creation) is not part of a step: do it now
-    # (no kernel launch), so that timed steps measure the hot path even with --warmup 0
-    R.prepare(b, flags)
+    def max_over_ranks(x):
+        el = torch.tensor([x], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        return float(el.item())
+
     if world > 1:
-        # communicators and point-to-point channels are created lazily on first use: do that outside the timed region
-        # even when --warmup 0 is requested
-        tiny = torch.zeros(8, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        # communicators and point-to-point channels are created lazily on first use: do that outside every timed region
+        tiny = torch.zeros(8, dtype=torch.float64, device=cdev)
         dist.gather(tiny, [torch.empty_like(tiny) for _ in range(world)] if rank == 0 else None, dst=0)
         dist.all_reduce(tiny)
-    for _ in range(args.warmup):
-        tr.render_frame(dst=0)
-    sync()
-    R.kernel_time_total(b, reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        frame = tr.render_frame(dst=0)             # asynchronous: no host stop between frames
-    sync()
-    elapsed = time.perf_counter() - t0
-    # HIP events around every kernel on its own launch stream, summed by the library (no host stop after each frame)
-    k_total_ms, k_launches = R.kernel_time_total(b)
-    assert k_launches == args.steps
-    stats = R.last_stats(b)
-    n_flush = R.last_flush_count(b)
-    el = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
 
-    if rank == 0:
-        assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
-        mean_radiance = float(torch.nan_to_num(frame).mean().item()) / w.spp
-        value = w.samples * args.steps / elapsed / 1e6
-        cpu, bps = None, workloads.BYTES_PER_SAMPLE.get(w.key)
-        if world == 1 and args.cpu_spp != 0 and not args.f32:
-            cpu, bps = cpu_baseline(w, args.cpu_spp, earth)
-        k_ms = k_total_ms / k_launches
+    def run(w, steps, warmup, warm_spp=None):
+        """Time `steps` frames of workload `w` (after `warmup` untimed ones; `warm_spp` renders the warm-up frames at a reduced
+        sample count through the same kernel and scene).  Returns what rank 0 needs for its line."""
+        nonlocal earth
+        if w.scene == "final" and earth is None:
+            earth = scenes.load_earthmap()          # the reference's own 1024x512 texture (tests/golden/earthmap.jpg)
+        b, cam, bg = workloads.build(w, be, earth)
+        if args.sah:
+            R.set_bvh_builder(b, R.RT_BVH_SAH)
+        # one-time initialisation (scene flatten + upload, code-object load, event creation) is not part of a step
+        R.prepare(b, flags)
+        if warmup:
+            tw = D.TileRenderer(b, cam, bg, w.W, w.H, warm_spp or w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world,
+                                pipeline=args.pipeline)
+            for _ in range(warmup):
+                tw.render_frame(dst=0)
+            sync()
+            del tw
+        tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world,
+                            pipeline=args.pipeline)
+        sync()
+        R.kernel_time_total(b, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            frame = tr.render_frame(dst=0)             # asynchronous: no host stop between frames
+        sync()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        # HIP events around every kernel on its own launch stream, summed by the library (no host stop after each frame)
+        k_total_ms, k_launches = R.kernel_time_total(b)
+        assert k_launches == steps
+        res = {"w": w, "elapsed": elapsed, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
+               "pipeline": tr.pipeline}
+        if rank == 0:
+            assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
+            res["mean_radiance"] = float(torch.nan_to_num(frame).mean().item()) / w.spp
         n_px = w.W * w.H                     # real (unpadded) pixels rank 0's launch owns
         local_px = sum(max(0, min(n_px, (t + 1) * args.tile_px) - t * args.tile_px)
                        for t in D.local_tile_ids(w.W, w.H, args.tile_px, rank, world) if t * args.tile_px < n_px)
-        local_samples = local_px * w.spp
-        roof = None
-        if bps is not None:
-            achieved = bps * local_samples / (k_ms * 1e-3) / 1e9
-            traffic, traffic_src, valu_busy = pmc_traffic_bytes(w.key) if (world == 1 and not args.f32) else (None, None, None)
-            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                    "traffic": traffic, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE)", "traffic_source": traffic_src,
-                    "algorithmic_bytes_per_launch": bps * local_samples, "kernel": f"rt::pathtrace_kernel<{'float' if args.f32 else 'double'}, FEATS> (FEATS = 0 for the Cornell box; the leanest instantiation covering the scene)",
-                    "kernel_ms": k_ms, "bytes_per_sample": bps,
-                    "valu_busy_frac": valu_busy,        # from the same committed PMC passes: what actually limits the kernel
-                    "framebuffer_atomics_per_launch": 3 * n_flush,       # what the kernel itself counted: f64 atomic adds, 8 B each
-                    "framebuffer_atomic_bytes_per_launch": 24 * n_flush,
-                    "note": "algorithmic bytes (event x record-size model, SURVEY 8(d)); the scene is L2/LDS-resident, "
-                            "physical HBM traffic is ~ the framebuffer (see DESIGN.md / profiles/)"}
+        res["local_samples"] = local_px * w.spp
+        del tr, frame, b
+        torch.cuda.empty_cache()
+        return res
+
+    w = workloads.WORKLOADS[args.workload]
+    main_res = run(w, args.steps, args.warmup)
+    extra = []
+    if args.also.lower() != "none":
+        for key in args.also.split(","):
+            if key and key != w.key:
+                we = workloads.WORKLOADS[key]
+                extra.append(run(we, 1, 1, warm_spp=max(1, we.spp // 32)))
+
+    if rank == 0:
+        with_pmc = world == 1 and not args.f32 and not args.near_first and not args.sah
+        bps = workloads.BYTES_PER_SAMPLE[w.key]
+        roof, valu = roofline_of(w, bps, main_res["local_samples"], main_res["k_ms"], main_res["n_flush"], kernel_name_of(w, args.f32), with_pmc)
+        cpu = None
+        if world == 1 and args.cpu_spp != 0 and not args.f32:
+            cpu = cpu_baseline(w, args.cpu_spp, earth)
+        st = main_res["stats"]
+        others = {}
+        for r in extra:
+            we = r["w"]
+            ro, va = roofline_of(we, workloads.BYTES_PER_SAMPLE[we.key], r["local_samples"], r["k_ms"], r["n_flush"], kernel_name_of(we, args.f32), with_pmc)
+            others[we.key] = {"workload": we.describe(), "value": we.samples / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 1,
+                              "warmup": f"1 frame at {max(1, we.spp // 32)} spp (same kernel and scene)", "ms_per_step": r["elapsed"] * 1e3,
+                              "kernel_ms": r["k_ms"], "frac": ro["frac"], "bytes_per_sample": ro["bytes_per_sample"],
+                              "achieved_GBps": ro["achieved"], "traffic": ro["traffic"], "traffic_source": ro["traffic_source"],
+                              "valu_roofline": va, "kernel": ro["kernel"],
+                              "lane_utilisation": r["stats"]["live_lane_iterations"] / max(1, 64 * r["stats"]["wave_iterations"]),
+                              "nonfinite_samples_rank0": r["stats"]["nonfinite_samples"], "mean_radiance": r["mean_radiance"]}
         out = {
-            "metric": "Msamples/s (pixels x spp / s)", "value": value, "unit": "Msamples/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "metric": "Msamples/s (pixels x spp / s)", "value": w.samples * args.steps / main_res["elapsed"] / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["elapsed"] / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32" if args.f32 else "f64", "data": "synthetic",
             "config": {"workload": f"{w.key}: {w.describe()}", "tile_px": args.tile_px, "seed": "0x5EED",
                        "parallelism": f"tiles interleaved over {world} GPU(s) + 1 gather",
-                       "frames_in_flight": tr.pipeline},
-            "roofline": roof, "cpu_baseline": cpu,
-            "lane_utilisation": stats["live_lane_iterations"] / max(1, 64 * stats["wave_iterations"]),
-            "nonfinite_samples_rank0": stats["nonfinite_samples"], "mean_radiance": mean_radiance,
+                       "frames_in_flight": main_res["pipeline"]},
+            "roofline": roof, "valu_roofline": valu, "cpu_baseline": cpu, "workloads": others,
+            "lane_utilisation": st["live_lane_iterations"] / max(1, 64 * st["wave_iterations"]),
+            "nonfinite_samples_rank0": st["nonfinite_samples"], "mean_radiance": main_res["mean_radiance"],
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -57,7 +57,13 @@ static const double PI = 3.14159265358979323846264338327950288;  // std::f64::co
 static const double F64_MAX = std::numeric_limits<double>::max();
 static const double F64_INF = std::numeric_limits<double>::infinity();
 
-// Event counters for the algorithmic-bytes model.
+// Event counters for the algorithmic-bytes model.  -DORC_NO_COUNTERS (liboracle_nocount.so, what bench.py's
+// cpu_baseline leg times) compiles every count out, so that the timed CPU baseline carries no bookkeeping of ours.
+#ifdef ORC_NO_COUNTERS
+#define ORC_COUNT(expr) ((void)0)
+#else
+#define ORC_COUNT(expr) (expr)
+#endif
 struct Counters {
     uint64_t samples = 0, world_hits = 0, bvh_nodes = 0, rect_tests = 0, sphere_tests = 0,
              msphere_tests = 0, tri_tests = 0, xforms = 0, medium_tests = 0, shades = 0,
@@ -298,7 +304,7 @@ struct NoiseTexture : Texture {
     Perlin noise; double scale;
     NoiseTexture(double sc, Sampler& s) : noise(s), scale(sc) {}     // texture.rs:63-68
     Color mapping(double, double, const Vec3& p, Sampler& s) const override {   // texture.rs:71-79
-        s.c.perlin_evals += 7;
+        ORC_COUNT(s.c.perlin_evals += 7);
         return Color(1.0, 1.0, 1.0) * 0.5 * (1.0 + std::sin(scale * p.z() + 10.0 * noise.turb(p, scale, 7)));
     }
 };
@@ -312,7 +318,7 @@ struct ImageTexture : Texture {
         if (i > w - 1) i = w - 1;
         if (j > h - 1) j = h - 1;
         size_t idx = 3 * i + 3 * w * j;
-        s.c.texels++;
+        ORC_COUNT(s.c.texels++);
         return Color((double)data[idx] / 255.0, (double)data[idx + 1] / 255.0, (double)data[idx + 2] / 255.0);
     }
 };
@@ -692,7 +698,7 @@ struct Sphere : Hittable {
     Point3 center; double radius; const Material* material;
     Sphere(const Point3& c, double r, const Material* m) : center(c), radius(r), material(m) {}
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
-        s.c.sphere_tests++;
+        ORC_COUNT(s.c.sphere_tests++);
         return sphere_hit_body(center, radius, material, r, t_min, t_max, rec);
     }
     bool bounding_box(double, double, AABB& out) const override {      // sphere.rs:97-102
@@ -700,7 +706,7 @@ struct Sphere : Hittable {
         return true;
     }
     double pdf_value(const Point3& o, const Vec3& v, Sampler& s) const override {   // sphere.rs:104-112
-        s.c.light_pdf++;
+        ORC_COUNT(s.c.light_pdf++);
         HitRecord rec;
         if (sphere_hit_body(center, radius, material, Ray(o, v, 0.0), 0.001, F64_MAX, rec)) {
             double cos_theta_max = std::sqrt(1.0 - radius * radius / sq_of_len(center - o));
@@ -710,7 +716,7 @@ struct Sphere : Hittable {
         return 0.0;
     }
     Vec3 random(const Vec3& o, Sampler& s) const override {            // sphere.rs:114-119
-        s.c.light_random++;
+        ORC_COUNT(s.c.light_random++);
         Vec3 direction = center - o;
         double distance_squared = sq_of_len(direction);
         ONB uvw = ONB::build_from_w(direction);
@@ -725,7 +731,7 @@ struct MovingSphere : Hittable {
         return center0 + (time - time0) / (time1 - time0) * (center1 - center0);
     }
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
-        s.c.msphere_tests++;
+        ORC_COUNT(s.c.msphere_tests++);
         return sphere_hit_body(center(r.time()), radius, material, r, t_min, t_max, rec);
     }
     bool bounding_box(double, double, AABB& out) const override {      // sphere.rs:191-201
@@ -766,7 +772,7 @@ struct AARect : Hittable {
         return true;
     }
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {
-        s.c.rect_tests++;
+        ORC_COUNT(s.c.rect_tests++);
         return hit_body(r, t_min, t_max, rec);
     }
     bool bounding_box(double, double, AABB& out) const override {      // rect.rs:83-89 (ignores `plane`, reference quirk B4)
@@ -774,7 +780,7 @@ struct AARect : Hittable {
         return true;
     }
     double pdf_value(const Point3& o, const Vec3& v, Sampler& s) const override {    // rect.rs:91-101
-        s.c.light_pdf++;
+        ORC_COUNT(s.c.light_pdf++);
         HitRecord rec;
         if (hit_body(Ray(o, v, 0.0), 0.001, F64_INF, rec)) {
             double area = (a1 - a0) * (b1 - b0);
@@ -785,7 +791,7 @@ struct AARect : Hittable {
         return 0.0;
     }
     Vec3 random(const Vec3& o, Sampler& s) const override {            // rect.rs:103-111
-        s.c.light_random++;
+        ORC_COUNT(s.c.light_random++);
         int ki, ai, bi;
         plane_axes(plane, ki, ai, bi);
         Vec3 random_point(0.0, 0.0, 0.0);
@@ -820,7 +826,7 @@ struct Triangle : Hittable {
     Point3 vertices[3]; const Material* material;
     Triangle(const Point3& a, const Point3& b, const Point3& c, const Material* m) : vertices{a, b, c}, material(m) {}
     bool hit(const Ray& r, double t_min, double t_max, Sampler& sm, HitRecord& rec) const override {   // tri.rs:24-57
-        sm.c.tri_tests++;
+        ORC_COUNT(sm.c.tri_tests++);
         Vec3 s = r.origin() - vertices[0];
         Vec3 e1 = vertices[1] - vertices[0];
         Vec3 e2 = vertices[2] - vertices[0];
@@ -854,7 +860,7 @@ struct Translate : Hittable {
     const Hittable* hittable; Vec3 offset;
     Translate(const Hittable* h, const Vec3& o) : hittable(h), offset(o) {}
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // translate.rs:22-30
-        s.c.xforms++;
+        ORC_COUNT(s.c.xforms++);
         Ray translated_ray(r.origin() - offset, r.direction(), r.time());
         if (!hittable->hit(translated_ray, t_min, t_max, s, rec)) return false;
         rec.position = rec.position + offset;
@@ -905,7 +911,7 @@ struct Rotate : Hittable {
         }
     }
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // rotate.rs:77-106
-        s.c.xforms++;
+        ORC_COUNT(s.c.xforms++);
         int r_axis, a_axis, b_axis;
         axis_index(axis, r_axis, a_axis, b_axis);
         Vec3 origin = r.origin();
@@ -934,7 +940,7 @@ struct ConstantMedium : Hittable {
     const Hittable* boundary; double density; Isotropic phase_function;
     ConstantMedium(const Hittable* b, double d, const Texture* t, const bool* opt) : boundary(b), density(d), phase_function(t, opt) {}
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // medium.rs:27-61
-        s.c.medium_tests++;
+        ORC_COUNT(s.c.medium_tests++);
         HitRecord hit1, hit2;
         if (boundary->hit(r, -F64_MAX, F64_MAX, s, hit1)) {
             if (boundary->hit(r, hit1.t + 0.0001, F64_MAX, s, hit2)) {
@@ -992,7 +998,7 @@ struct BVH : Hittable {
         }
     }
     bool hit(const Ray& r, double t_min, double t_max, Sampler& s, HitRecord& rec) const override {   // bvh.rs:77-91
-        s.c.bvh_nodes++;
+        ORC_COUNT(s.c.bvh_nodes++);
         if (!bbox.hit(r, t_min, t_max)) return false;
         if (leaf) return leaf->hit(r, t_min, t_max, s, rec);
         HitRecord l;
@@ -1036,14 +1042,14 @@ struct Camera {
 // ---------------------------------------------------------------- src/main.rs:41-120  ray_color
 static Color ray_color(const Ray& ray, const Color& background, const Hittable* world, const HittableList* lights, uint64_t depth, Sampler& s) {
     if (depth <= 0) return Color(0.0, 0.0, 0.0);                                                     // main.rs:42-45
-    s.c.world_hits++;
+    ORC_COUNT(s.c.world_hits++);
     HitRecord rec;
     if (world->hit(ray, 0.00001, F64_INF, s, rec)) {                                                 // main.rs:48
-        s.c.shades++;
+        ORC_COUNT(s.c.shades++);
         Color emitted = rec.material->emitted(rec, s);                                               // main.rs:62
         ScatterRecord srec;
         if (rec.material->scatter_mc_method(ray, rec, s, srec)) {                                    // main.rs:86
-            s.c.bounces++;
+            ORC_COUNT(s.c.bounces++);
             if (srec.kind == ScatterRecord::Specular) {                                              // main.rs:89-91
                 return srec.attenuation * ray_color(srec.specular_ray, background, world, lights, depth - 1, s);
             }
@@ -1095,9 +1101,10 @@ static inline Color sample_pixel(const Scene& sc, const Camera& cam, const Color
     double v = ((double)j + random_v) / (double)(H - 1);
     Ray r = cam.get_ray(u, v, smp);
     Color c = ray_color(r, bg, sc.world, &sc.lights, depth, smp);
-    smp.c.samples++;
-    if (!(std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2]))) smp.c.nonfinite++;
-    cnt.add(smp.c);
+    ORC_COUNT(smp.c.samples++);
+    ORC_COUNT(smp.c.nonfinite += (std::isfinite(c[0]) && std::isfinite(c[1]) && std::isfinite(c[2])) ? 0 : 1);
+    ORC_COUNT(cnt.add(smp.c));
+    (void)cnt;
     return c;
 }
 
@@ -1228,23 +1235,43 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
         work(0);
         for (auto& t : th) t.join();
     } else {
+        // rayon keeps one global pool and forks/joins the sample range of ONE pixel at a time (main.rs:811-830): persistent workers
+        // here too (creating threads per pixel would time thread start-up, not the path), released per pixel by a generation
+        // counter, joined by a completion counter; the per-pixel sum is then taken in sample order.
         std::vector<Color> buf(spp);
+        std::atomic<uint64_t> gen(0);
+        std::atomic<uint32_t> next(0), done(0);
+        std::atomic<bool> quit(false);
+        uint32_t cur_i = 0, cur_j = 0;
+        auto run_pixel = [&](int tid) {
+            for (;;) {
+                uint32_t k0 = next.fetch_add(16);
+                if (k0 >= spp) break;
+                for (uint32_t k = k0; k < std::min(spp, k0 + 16); k++)
+                    buf[k] = sample_pixel(sc, cam, background, W, H, cur_i, cur_j, k, depth, seed, cnts[(size_t)tid]);
+            }
+        };
+        auto worker = [&](int tid) {
+            uint64_t seen = 0;
+            for (;;) {
+                while (gen.load(std::memory_order_acquire) == seen) {
+                    if (quit.load(std::memory_order_acquire)) return;
+                    std::this_thread::yield();
+                }
+                seen++;
+                run_pixel(tid);
+                done.fetch_add(1, std::memory_order_release);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; t++) th.emplace_back(worker, t);
         for (uint32_t row = row0; row < row1; row++) {
-            uint32_t j = H - 1 - row;
             for (uint32_t i = 0; i < W; i++) {
-                std::atomic<uint32_t> next(0);
-                auto work = [&](int tid) {
-                    for (;;) {
-                        uint32_t k0 = next.fetch_add(16);
-                        if (k0 >= spp) break;
-                        for (uint32_t k = k0; k < std::min(spp, k0 + 16); k++)
-                            buf[k] = sample_pixel(sc, cam, background, W, H, i, j, k, depth, seed, cnts[(size_t)tid]);
-                    }
-                };
-                std::vector<std::thread> th;
-                for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
-                work(0);
-                for (auto& t : th) t.join();
+                cur_i = i; cur_j = H - 1 - row;
+                next.store(0); done.store(0);
+                gen.fetch_add(1, std::memory_order_release);
+                run_pixel(0);
+                while (done.load(std::memory_order_acquire) != (uint32_t)(nthreads - 1)) std::this_thread::yield();
                 Color pixel(0.0, 0.0, 0.0);
                 size_t p = (size_t)row * W + i;
                 for (uint32_t k = 0; k < spp; k++) {
@@ -1254,6 +1281,8 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
                 for (int ch = 0; ch < 3; ch++) out_sum[p * 3 + (size_t)ch] = pixel[ch];
             }
         }
+        quit.store(true, std::memory_order_release);
+        for (auto& t : th) t.join();
     }
     if (counters) {
         Counters tot;

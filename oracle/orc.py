@@ -33,6 +33,21 @@ RECORD_BYTES = {"bvh_nodes": 32, "rect_tests": 24, "sphere_tests": 20, "msphere_
 FRAMEBUFFER_BYTES_PER_PIXEL = 12
 
 _backend = None
+NOCOUNT_LIB_PATH = os.path.join(_HERE, "_build", "liboracle_nocount.so")
+BUILD_INFO = {"compiler": "g++ (see `g++ --version` of the build host; 11.4 in the round-2 image)",
+              "flags": "-O3 -std=c++17 -ffp-contract=off -fno-fast-math -pthread, baseline x86-64 (no -march=native: built on one host, "
+                       "run on another); event counters compiled out (-DORC_NO_COUNTERS)"}
+_nocount = None
+
+
+def load_nocount() -> Backend:
+    """The oracle built with every event counter compiled out (bench.py's cpu_baseline leg): same arithmetic, no bookkeeping."""
+    global _nocount
+    if _nocount is None:
+        if not os.path.exists(NOCOUNT_LIB_PATH):
+            build()
+        _nocount = _declare(C.CDLL(NOCOUNT_LIB_PATH))
+    return _nocount
 
 
 def build():
@@ -46,7 +61,11 @@ def load() -> Backend:
     path = os.environ.get("ORC_LIB", LIB_PATH)          # ORC_LIB: the sanitizer build (tests/test_sanitizers.py)
     if not os.path.exists(path):
         build()
-    lib = C.CDLL(path)
+    _backend = _declare(C.CDLL(path))
+    return _backend
+
+
+def _declare(lib) -> Backend:
     be = Backend(lib, "orc_")
     cam_p = C.POINTER(CameraParams)
     lib.orc_render.restype = C.c_int
@@ -81,7 +100,6 @@ def load() -> Backend:
     lib.orc_brdf_pdf_value.argtypes = [C.c_void_p, C.c_int, d3, d3, d3]
     lib.orc_brdf_pdf_generate.argtypes = [C.c_void_p, C.c_int, d3, d3, C.c_void_p, d3]
     lib.orc_ray_color.argtypes = [C.c_void_p, d3, d3, C.c_double, d3, C.c_uint64, C.c_void_p, d3]
-    _backend = be
     return be
 
 
@@ -95,8 +113,9 @@ def hardware_threads() -> int:
 
 def render(b, cam, background, W, H, spp, max_depth, seed=0x5EED, want_samples=False, want_counters=False,
            nthreads=0, mode=0, rows=None):
-    """Per-pixel sums (H, W, 3) f64 in output order; optionally (H, W, spp, 3) samples and the event counters."""
-    be = load()
+    """Per-pixel sums (H, W, 3) f64 in output order; optionally (H, W, spp, 3) samples and the event counters.  The scene `b`
+    decides which build of the oracle runs (the counting one from load(), or load_nocount())."""
+    be = b.b
     out = np.zeros((H, W, 3), dtype=np.float64)
     samples = np.zeros((H, W, spp, 3), dtype=np.float64) if want_samples else None
     cnt = np.zeros(len(COUNTER_NAMES), dtype=np.uint64)

@@ -32,10 +32,11 @@ WORKLOADS = {
     "C5": Workload("C5", "cornell", 3840, 2160, 8192, 50, "Cornell Box 4K strong-scaling case"),
 }
 
-# Algorithmic bytes per sample (SURVEY.md §8(d) event x record-size model), measured by the CPU oracle's event
-# counters on each workload's own pixel grid at 16 spp under the default seed (tools/measure_bytes_per_sample.py;
-# the numbers and the run are recorded in BASELINE.md).  Used for `roofline.achieved` when the oracle is not run.
-BYTES_PER_SAMPLE = {"C2": 1466.0}
+# Algorithmic bytes per sample (SURVEY.md §8(d) event x record-size model), measured by the CPU oracle's event counters on each
+# workload's own pixel grid under the default seed (tests/sweeps/measure_bytes_per_sample.py, round 2: C1 at its 64 spp, C2-C4 at
+# 16 spp, C5 at 4 spp; the run is recorded in BASELINE.md).  ONE committed value per workload: bench.py's `roofline.achieved` uses it
+# at every N, and never re-measures it.  (C5 is C2's scene on a 16:9 frame: the side columns look past the box, so fewer bounces.)
+BYTES_PER_SAMPLE = {"C1": 5158.1, "C2": 1473.4, "C3": 2988.0, "C4": 2160.2, "C5": 1039.8}
 
 
 def build(w: Workload, backend, earth=None):

@@ -496,6 +496,65 @@ def test_full_size_final_scene_properties(pbe, obe, orc_mod, earth):
     print(f"C3 {w.W}x{w.H}x{w.spp} f64: {ms:.0f} ms, {w.samples / ms / 1e3:.0f} Msamples/s, {n_bad} non-finite samples")
 
 
+def test_c1_full_size_per_sample_against_the_oracle(pbe, obe, orc_mod):
+    """BASELINE config 1 at its full size — random_scene 400x225, 64 spp, depth 8 (5.76 M samples; the reference's CPU-runnable
+    case, src/main.rs:153-210 with the 16:9 frame BASELINE names): every sample against the oracle, same tolerance as the small cases."""
+    from raytracinginrust_amd import workloads
+    w = workloads.WORKLOADS["C1"]
+    pb, pcam, pbg = workloads.build(w, pbe)
+    ob, ocam, obg = workloads.build(w, obe)
+    ref, rs, cnt = orc_mod.render(ob, ocam, obg, w.W, w.H, w.spp, w.max_depth, want_samples=True, want_counters=True)
+    got, gs = R.render(pb, pcam, pbg, w.W, w.H, w.spp, w.max_depth, want_samples=True)
+    n_bad, max_d, bad = _compare_samples(gs, rs)
+    assert n_bad <= MAX_DIVERGED, f"{n_bad} of {w.samples} samples diverged"
+    assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+    clean = ~bad.any(axis=-1)
+    fin = np.isfinite(ref)
+    dp = np.abs(np.where(fin, got, 0.0) - np.where(fin, ref, 0.0))
+    assert np.all(dp[clean] <= SAMPLE_RTOL * (w.spp + np.abs(np.where(fin, ref, 0.0))[clean]))
+    a, c = R.format_image(got, w.spp), R.format_image(ref, w.spp)
+    assert (a != c).sum() <= 5 and np.abs(a.astype(int) - c.astype(int)).max() <= 1
+    print(f"C1 {w.W}x{w.H}x{w.spp}: {n_bad} diverged, max |gpu - oracle| per sample {max_d:.2e}, "
+          f"{(gs.view(np.uint64) == rs.view(np.uint64)).all(axis=-1).mean():.3f} of samples bit-identical")
+
+
+def test_c5_full_sample_count(pbe, obe, orc_mod):
+    """BASELINE config 5 at its real sample count: Cornell box 3840x2160 (src/main.rs:579-583 scaled), 8192 spp, depth 50 =
+    67.9 G samples (pixels x spp > 2^32; 32 work chunks per pixel).  The whole frame on ONE GPU, then rank 0's share of the
+    8-GPU decomposition at the same spp: (1) no non-finite sample; (2) the share's tiles equal the whole frame's pixels to
+    summation-order rounding (sharded == unsharded at full spp); (3) the share is reproducible; (4) the frame mean matches the
+    oracle's on a coarse grid of the same image within Monte-Carlo error."""
+    import torch
+    from raytracinginrust_amd import workloads
+    w = workloads.WORKLOADS["C5"]
+    assert w.W * w.H * w.spp > 2 ** 32
+    b, cam, bg = workloads.build(w, pbe)
+    full = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
+    ms = R.last_kernel_ms(b)
+    assert R.last_stats(b)["nonfinite_samples"] == 0 and np.isfinite(full).all()
+    tile = D.DEFAULT_TILE_PX
+    tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, tile_px=tile, rank=0, world=8)
+    share = tr.render_local().clone(); torch.cuda.synchronize()
+    ms_share = R.last_kernel_ms(b)
+    assert R.last_stats(b)["nonfinite_samples"] == 0
+    again = tr.render_local().clone(); torch.cuda.synchronize()
+    share, again = share.cpu().numpy(), again.cpu().numpy()
+    assert np.all(np.abs(share - again) <= 1e-12 * (w.spp + np.abs(share)))
+    flat = full.reshape(-1, 3)
+    n_px = w.W * w.H
+    for q, t in enumerate(D.local_tile_ids(w.W, w.H, tile, 0, 8)):
+        lo, hi = t * tile, min(n_px, (t + 1) * tile)
+        if lo >= n_px:
+            assert not share[q].any()                            # padding tile
+            continue
+        assert np.all(np.abs(share[q, : hi - lo] - flat[lo:hi]) <= 1e-12 * (w.spp + np.abs(flat[lo:hi])))
+    ob, ocam, obg = workloads.build(w, obe)
+    coarse = orc_mod.render(ob, ocam, obg, 192, 108, 64, w.max_depth, seed=17)
+    assert full.mean() / w.spp == pytest.approx(coarse.mean() / 64, rel=0.02)
+    print(f"C5 {w.W}x{w.H}x{w.spp} f64 on one GPU: {ms / 1e3:.2f} s, {w.samples / ms / 1e3:.0f} Msamples/s; rank 0's 1/8 share {ms_share:.0f} ms "
+          f"(x8 = {8 * ms_share / 1e3:.2f} s)")
+
+
 def test_f32_variant_statistical_parity(pbe):
     """RT_F32 is the throughput variant: same estimator in f32, so only statistical agreement is claimed."""
     b, cam, bg = _cornell(pbe)
@@ -532,7 +591,7 @@ def test_cxx_host_final_scene_with_jpeg_ingest(pbe):
     Python-built scene gives with the same decoded texels."""
     import subprocess
     exe = os.path.join(os.path.dirname(_lib.LIB_PATH), "..", "host", "rtrender")
-    jpg = scenes.asset_path("earthmap_256x128_444.jpg")
+    jpg = scenes.asset_path("earthmap.jpg")                  # the reference's own 1024x512 asset (src/main.rs:491-495)
     W, H, spp, depth = 40, 40, 8, 20
     txt = subprocess.run([exe, "--scene", "final", "--earth", jpg, "--width", str(W), "--height", str(H), "--spp", str(spp), "--depth", str(depth)],
                          check=True, capture_output=True, text=True).stdout.split("\n")

@@ -10,5 +10,8 @@ for f in sorted(glob.glob(os.path.join(root, '*', '*', '*counter_collection.csv'
 out = []
 for k, v in res.items():
     out.append(f"{k},{sum(v)/len(v):.6g},{len(v)}")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracinginrust_amd import buildinfo
+out.append(f"kernel_source_id,{buildinfo.kernel_source_id()},0")      # bench.py quotes these counters only on the same kernels
 open(os.path.join(root, 'summary.csv'), 'w').write("counter,mean_per_dispatch,dispatches\n" + "\n".join(out) + "\n")
 print("\n".join(out))

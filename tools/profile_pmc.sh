@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 pass() {  # name counters...
   local name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-spp 0 "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- python3 /root/repo/bench.py --steps 2 --warmup 1 --cpu-spp 0 --also none "${BENCH_ARGS[@]}" > $OUT/$name.log 2>&1
   tail -1 $OUT/$name.log | cut -c1-200
 }
 BENCH_ARGS=("$@")
