@@ -39,6 +39,22 @@
 #ifndef RT_SHARED_DIV3
 #define RT_SHARED_DIV3 (RT_TU == 2)
 #endif
+// Minimum resident waves per SIMD the register allocation is held to (512 VGPRs / waves, in steps of 8), per kernel family.
+// *Measured* (round 2, A/B in one process, with -disable-machine-licm): the lock-step BVH kernels are faster at 4 waves with a few
+// dozen spilled registers than at 3 without (random spheres +6.6 %, final scene +10 %); the persistent-traversal mesh kernel is not
+// (131 spills at 4 waves: teapot room -26 %).
+#ifndef RT_WAVES_LEAN
+#define RT_WAVES_LEAN 4
+#endif
+#ifndef RT_WAVES_BVH
+#define RT_WAVES_BVH 4
+#endif
+#ifndef RT_WAVES_PERSIST
+#define RT_WAVES_PERSIST 3
+#endif
+#ifndef RT_WAVES_PBR
+#define RT_WAVES_PBR 3
+#endif
 #ifndef RT_WW_NUM
 #define RT_WW_NUM 3u
 #define RT_WW_DEN 8u
@@ -1379,7 +1395,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
 
 // ------------------------------------------------------------------ the kernel
 template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256, (FEATS == 0u ? 4 : ((FEATS & F_PBR) ? 2 : 3))) pathtrace_kernel(const KParams<T> P) {
+__global__ void __launch_bounds__(256, (FEATS == 0u ? RT_WAVES_LEAN : ((FEATS & F_PBR) ? RT_WAVES_PBR : ((FEATS & F_PERSIST) ? RT_WAVES_PERSIST : RT_WAVES_BVH)))) pathtrace_kernel(const KParams<T> P) {
     // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
@@ -1424,7 +1440,9 @@ template int occupancy_lean<double>(size_t);
 template int occupancy_lean<float>(size_t);
 #endif
 
-#if RT_TU != 1
+#if defined(RT_KRES_ONLY)      // tools/kres.py: one instantiation only (compile-time exploration, never the product build)
+template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<double>);
+#elif RT_TU != 1
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH

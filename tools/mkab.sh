@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build a kernel variant as csrc/ab/<name>.so for A/B timing with tools/ab.py (never shipped: csrc/ab/ is emptied before a round ends).
+# usage: tools/mkab.sh <name> "<extra flags for the lean TU>" "<extra flags for the other TU>" [kernel source (default rt_kernel.hip)]
+set -e
+cd "$(dirname "$0")/../raytracinginrust_amd/csrc"
+name=$1; f1=$2; f2=$3; src=${4:-rt_kernel.hip}
+mkdir -p ab
+BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 -I."
+/opt/rocm/bin/hipcc $BASE -O2 -mllvm -enable-misched=0 $f1 -DRT_TU=1 -c $src -o ab/${name}_lean.o &
+/opt/rocm/bin/hipcc $BASE $f2 -DRT_TU=2 -c $src -o ab/${name}_rest.o &
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/$name.so ab/${name}_lean.o ab/${name}_rest.o rt_host.o rt_flatten.o rt_jpeg.o rt_obj.o
+rm -f ab/${name}_lean.o ab/${name}_rest.o
+echo built ab/$name.so
