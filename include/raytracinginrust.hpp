@@ -151,6 +151,14 @@ inline std::vector<double> render(Scene& s, const Camera& cam, Color background,
     if (rt_render(s.raw(), &cam.c, background.e, W, H, samples_per_pixel, max_depth, seed, flags, out.data()) != 0) throw Error(rt_last_error());
     return out;
 }
+// The same loop on several GPUs of this node (device_mask: bit d = HIP device d, 0 = all visible): tiles dealt round-robin, one RCCL
+// gather to the first device, un-permuted there (rt_render_multi).
+inline std::vector<double> render_multi(Scene& s, const Camera& cam, Color background, uint32_t W, uint32_t H, uint32_t samples_per_pixel,
+                                        uint32_t max_depth, uint32_t device_mask, uint64_t seed = 0x5EED, uint32_t flags = RT_F64, uint32_t tile_px = 0) {
+    std::vector<double> out((size_t)W * H * 3);
+    if (rt_render_multi(s.raw(), &cam.c, background.e, W, H, samples_per_pixel, max_depth, seed, flags, device_mask, tile_px, out.data()) != 0) throw Error(rt_last_error());
+    return out;
+}
 // main.rs:767-769,832
 inline void write_ppm(const char* path, const std::vector<double>& rgb_sum, uint32_t W, uint32_t H, uint64_t spp) {
     if (rt_write_ppm(path, rgb_sum.data(), W, H, spp) != 0) throw Error(rt_last_error());

@@ -49,6 +49,8 @@ enum {
                               shades / regenerates (mesh kernels).  Chosen automatically for a triangle-mesh BVH that stands
                               beside other top-level objects (most rays never enter it); this flag forces it on ...            */
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
+    RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
+                              exercises the same collective calls as an 8-GPU node)                                          */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
                               old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };
@@ -157,6 +159,17 @@ int rt_render_device(rt_scene*, const rt_camera*, const double background[3], ui
                      uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
                      uint32_t tile_px, uint32_t rank, uint32_t world_size,
                      void* d_out, size_t d_out_bytes, void* hip_stream);
+/* The whole frame on several GPUs of this node from ONE call: what a host that owns the node's GPUs itself (the reference's `main`,
+ * src/main.rs:767-835) calls instead of rt_render.  device_mask: bit d selects HIP device d (0 = every visible device).  The scene
+ * is replicated on each selected device; tiles of tile_px output-order pixels (0 = the default, 67) are dealt round-robin, each
+ * device renders its share with one persistent launch, ONE ncclGather (RCCL over xGMI; communicators from ncclCommInitAll, cached
+ * with the scene; librccl is loaded on first use) brings the packed tiles to the first selected device, which un-permutes them on the
+ * device; rgb_sum_out receives W*H*3 doubles in output order, as from rt_render.  Synchronous.  rt_last_multi_ms: [0] slowest
+ * device's kernel, [1] gather (including the wait for the slowest device), [2] un-permute, [3] whole call, in ms. */
+int rt_render_multi(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
+                    uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
+                    uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out);
+int rt_last_multi_ms(rt_scene*, double out4[4]);
 /* How BVH objects are built when the scene is flattened (at the first render / rt_scene_prepare after a change).
  * RT_BVH_MEDIAN (default) is BVH::new, src/bvh.rs:18-73: widest axis, object median.  RT_BVH_SAH is an opt-in fast mode
  * (binned surface-area heuristic, one object per leaf as in the reference): same closest hits; the order in which

@@ -50,6 +50,10 @@ def load_path(path: str) -> Backend:
     lib.rt_render_samples.argtypes = common + [C.c_void_p, C.c_void_p]
     lib.rt_render_device.restype = C.c_int
     lib.rt_render_device.argtypes = common + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.rt_render_multi.restype = C.c_int
+    lib.rt_render_multi.argtypes = common + [C.c_uint32, C.c_uint32, C.c_void_p]
+    lib.rt_last_multi_ms.restype = C.c_int
+    lib.rt_last_multi_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.rt_kernel_time_total.restype = C.c_int
     lib.rt_kernel_time_total.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.c_int]
     lib.rt_last_flush_count.restype = C.c_int

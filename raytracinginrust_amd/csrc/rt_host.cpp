@@ -20,11 +20,11 @@ bool decode_jpeg_rgb8(const uint8_t* data, size_t size, std::vector<uint8_t>& rg
 bool parse_obj(const char* data, size_t size, const double offset[3], double scale, std::vector<double>& positions, std::vector<uint32_t>& indices, std::string& err);
 }
 
-struct rt_scene { Scene s; };
 struct rt_rng { Rng r; };
 
 static thread_local std::string g_err;
 static int set_err(const std::string& m) { g_err = m; return -1; }
+namespace rt { int set_error(const std::string& m) { return set_err(m); } }
 static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_err = m; return -1; }
 
 #define HIP_OK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { g_err = std::string(#call) + ": " + hipGetErrorString(e_); return -1; } } while (0)
@@ -59,22 +59,33 @@ rt_scene* rt_scene_create(void) { return new rt_scene(); }
 
 void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
-    free_device_scene(sc->s.dev64);
-    free_device_scene(sc->s.dev32);
-    for (Scene::LaunchSlot& l : sc->s.slots) {
-        if (l.recorded) (void)hipEventSynchronize((hipEvent_t)l.ev_stop);
-        free_dev(l.d_queue); free_dev(l.d_stats);
-        if (l.ev_start) (void)hipEventDestroy((hipEvent_t)l.ev_start);
-        if (l.ev_stop) (void)hipEventDestroy((hipEvent_t)l.ev_stop);
+    int cur = 0; (void)hipGetDevice(&cur);
+    rt::multi_release(sc->s);
+    for (Scene::DeviceCtx* c : sc->s.ctxs) {
+        (void)hipSetDevice(c->device);
+        free_device_scene(c->dev64);
+        free_device_scene(c->dev32);
+        for (Scene::LaunchSlot& l : c->slots) {
+            if (l.recorded) (void)hipEventSynchronize((hipEvent_t)l.ev_stop);
+            free_dev(l.d_queue); free_dev(l.d_stats);
+            if (l.ev_start) (void)hipEventDestroy((hipEvent_t)l.ev_start);
+            if (l.ev_stop) (void)hipEventDestroy((hipEvent_t)l.ev_stop);
+        }
+        free_dev(c->d_tiles); free_dev(c->d_gather); free_dev(c->d_frame);
+        if (c->stream) (void)hipStreamDestroy((hipStream_t)c->stream);
+        delete c;
     }
+    if (!sc->s.ctxs.empty()) (void)hipSetDevice(cur);
     delete sc;
 }
 const char* rt_scene_error(rt_scene* sc) { return sc->s.error.c_str(); }
 
 static void touch(rt_scene* sc) {
     sc->s.invalidate();
-    free_device_scene(sc->s.dev64);
-    free_device_scene(sc->s.dev32);
+    if (sc->s.ctxs.empty()) return;
+    int cur = 0; (void)hipGetDevice(&cur);
+    for (Scene::DeviceCtx* c : sc->s.ctxs) { (void)hipSetDevice(c->device); free_device_scene(c->dev64); free_device_scene(c->dev32); }
+    (void)hipSetDevice(cur);
 }
 int rt_scene_set_traversal_schedule(rt_scene* sc, uint32_t start_at, uint32_t stop_below, uint32_t leaf_share64) {
     if (!sc) return set_err("null argument");
@@ -397,9 +408,15 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     return 0;
 }
 
-template <typename T> DeviceScene<T>& dev_of(Scene& s);
-template <> DeviceScene<double>& dev_of<double>(Scene& s) { return s.dev64; }
-template <> DeviceScene<float>& dev_of<float>(Scene& s) { return s.dev32; }
+template <typename T> DeviceScene<T>& dev_of(Scene::DeviceCtx& c);
+template <> DeviceScene<double>& dev_of<double>(Scene::DeviceCtx& c) { return c.dev64; }
+template <> DeviceScene<float>& dev_of<float>(Scene::DeviceCtx& c) { return c.dev32; }
+// the context of the calling thread's current HIP device
+static int current_ctx(Scene& s, Scene::DeviceCtx** out) {
+    int dev = 0; HIP_OK(hipGetDevice(&dev));
+    *out = &s.ctx_for(dev);
+    return 0;
+}
 
 // A finished launch's kernel time joins the running total exactly once (rt_kernel_time_total).
 static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
@@ -413,11 +430,11 @@ static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
 }
 // The launch slot for `stream`: the one this stream used last, else an unused one, else the least recently used one once its
 // launch has finished.
-static int acquire_slot(Scene& s, hipStream_t stream, Scene::LaunchSlot** out) {
+static int acquire_slot(Scene& s, Scene::DeviceCtx& c, hipStream_t stream, Scene::LaunchSlot** out) {
     Scene::LaunchSlot* pick = nullptr;
-    for (Scene::LaunchSlot& l : s.slots) if (l.recorded && l.stream == (void*)stream) { pick = &l; break; }
-    if (!pick) for (Scene::LaunchSlot& l : s.slots) if (!l.recorded) { pick = &l; break; }
-    if (!pick) { pick = &s.slots[0]; for (Scene::LaunchSlot& l : s.slots) if (l.seq < pick->seq) pick = &l; }
+    for (Scene::LaunchSlot& l : c.slots) if (l.recorded && l.stream == (void*)stream) { pick = &l; break; }
+    if (!pick) for (Scene::LaunchSlot& l : c.slots) if (!l.recorded) { pick = &l; break; }
+    if (!pick) { pick = &c.slots[0]; for (Scene::LaunchSlot& l : c.slots) if (l.seq < pick->seq) pick = &l; }
     if (settle_slot(s, *pick)) return -1;             // also waits for a launch another stream may still be running in this slot
     if (!pick->d_queue) HIP_OK(hipMalloc(&pick->d_queue, 64));
     if (!pick->d_stats) HIP_OK(hipMalloc(&pick->d_stats, RT_STATS_BYTES));
@@ -446,7 +463,10 @@ template <typename T>
 int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                 uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
                 void* d_samples, hipStream_t stream) {
-    DeviceScene<T>& d = dev_of<T>(s);
+    Scene::DeviceCtx* cp = nullptr;
+    if (current_ctx(s, &cp)) return -1;
+    Scene::DeviceCtx& c = *cp;
+    DeviceScene<T>& d = dev_of<T>(c);
     if (ensure_uploaded<T>(s, d)) return -1;
     const HostFlat& f = s.flat;
     KParams<T> P;
@@ -483,12 +503,11 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     else { P.chunk_px = (CH + spp - 1) / spp; P.chunks_per_px = 1u; P.chunk_spp = spp; }
     P.n_coarse_px = 0;
     Scene::LaunchSlot* slot = nullptr;
-    if (acquire_slot(s, stream, &slot)) return -1;
+    if (acquire_slot(s, c, stream, &slot)) return -1;
     P.queue = (uint32_t*)slot->d_queue; P.stats = (unsigned long long*)slot->d_stats;
     P.out = (double*)d_out; P.samples_out = (double*)d_samples;
 
-    int dev = 0; HIP_OK(hipGetDevice(&dev));
-    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, dev));
+    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
@@ -514,7 +533,8 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
     HIP_OK(hipEventRecord((hipEvent_t)slot->ev_stop, stream));
     slot->recorded = true; slot->timed = false; slot->seq = ++s.launch_seq;
-    s.last_slot = (int)(slot - s.slots);
+    c.last_slot = (int)(slot - c.slots);
+    s.last_device = c.device;
     return 0;
 }
 
@@ -553,9 +573,11 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
     Scene& s = sc->s;
-    if (flags & RT_F32) { if (ensure_uploaded<float>(s, s.dev32)) return -1; }
-    else { if (ensure_uploaded<double>(s, s.dev64)) return -1; }
-    for (Scene::LaunchSlot& l : s.slots) {
+    Scene::DeviceCtx* cp = nullptr;
+    if (current_ctx(s, &cp)) return -1;
+    if (flags & RT_F32) { if (ensure_uploaded<float>(s, cp->dev32)) return -1; }
+    else { if (ensure_uploaded<double>(s, cp->dev64)) return -1; }
+    for (Scene::LaunchSlot& l : cp->slots) {
         if (!l.d_queue) HIP_OK(hipMalloc(&l.d_queue, 64));
         if (!l.d_stats) HIP_OK(hipMalloc(&l.d_stats, RT_STATS_BYTES));
         if (!l.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_start = e; }
@@ -569,9 +591,24 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     return 0;
 }
 
+} // extern "C"
+namespace rt {
+int device_kernel_ms(Scene& s, int device, float* ms) {
+    for (Scene::DeviceCtx* c : s.ctxs) if (c->device == device && c->last_slot >= 0) {
+        Scene::LaunchSlot& l = c->slots[c->last_slot];
+        HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
+        HIP_OK(hipEventElapsedTime(ms, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
+        return 0;
+    }
+    return set_err("no kernel has been launched on that device");
+}
+}
+extern "C" {
+
 int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
-    if (!sc || !ms_out || sc->s.last_slot < 0) return set_err("no kernel has been launched for this scene");
-    Scene::LaunchSlot& l = sc->s.slots[sc->s.last_slot];
+    Scene::DeviceCtx* c = sc ? sc->s.last_ctx() : nullptr;
+    if (!sc || !ms_out || !c || c->last_slot < 0) return set_err("no kernel has been launched for this scene");
+    Scene::LaunchSlot& l = c->slots[c->last_slot];
     HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
     HIP_OK(hipEventElapsedTime(ms_out, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
     return 0;
@@ -582,7 +619,7 @@ int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
 // for the launches still in flight.  For callers that keep several frames in flight and must not stop after each one.
 int rt_kernel_time_total(rt_scene* sc, double* ms_total, unsigned long long* n_launches, int reset) {
     if (!sc) return set_err("null argument");
-    for (Scene::LaunchSlot& l : sc->s.slots) if (settle_slot(sc->s, l)) return -1;
+    for (Scene::DeviceCtx* c : sc->s.ctxs) for (Scene::LaunchSlot& l : c->slots) if (settle_slot(sc->s, l)) return -1;
     if (ms_total) *ms_total = sc->s.kernel_ms_total;
     if (n_launches) *n_launches = sc->s.kernel_launches_timed;
     if (reset) { sc->s.kernel_ms_total = 0.0; sc->s.kernel_launches_timed = 0; }
@@ -591,11 +628,12 @@ int rt_kernel_time_total(rt_scene* sc, double* ms_total, unsigned long long* n_l
 // The kernel spreads its end-of-launch counter atomics over RT_STATS_ROWS copies of the counter block (row = block index mod
 // rows): 4096 waves adding to one address serialise in the L2 atomic unit.  Readers sum the rows.
 static int read_stats(rt_scene* sc, unsigned long long h[RT_STATS_SLOTS]) {
-    if (!sc || sc->s.last_slot < 0) return set_err("no kernel has been launched for this scene");
-    Scene::LaunchSlot& l = sc->s.slots[sc->s.last_slot];
+    Scene::DeviceCtx* c = sc ? sc->s.last_ctx() : nullptr;
+    if (!sc || !c || c->last_slot < 0) return set_err("no kernel has been launched for this scene");
+    Scene::LaunchSlot& l = c->slots[c->last_slot];
     HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
     unsigned long long raw[RT_STATS_ROWS * RT_STATS_SLOTS];
-    HIP_OK(hipMemcpy(raw, l.d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(raw, l.d_stats, sizeof(raw), hipMemcpyDeviceToHost));      // unified addressing: the pointer names its device
     for (uint32_t k = 0; k < RT_STATS_SLOTS; k++) { h[k] = 0; for (uint32_t r = 0; r < RT_STATS_ROWS; r++) h[k] += raw[r * RT_STATS_SLOTS + k]; }
     return 0;
 }

@@ -1451,7 +1451,10 @@ template <typename T, typename F, typename L> static auto dispatch(uint32_t scen
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
-    if ((scene_feats & ~FEATS_NO_PBR) == 0u) return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
+    if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
+        if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
+        return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
+    }
     return nf ? f(std::integral_constant<uint32_t, F_ALL | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, F_ALL>());
 }
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {

@@ -58,8 +58,6 @@ struct Scene {
 
     bool flat_valid = false;
     HostFlat flat;
-    DeviceScene<double> dev64;
-    DeviceScene<float> dev32;
     // Launch scratch (device queue counter + counter block, a pair of events), one set per stream in use: launches of one
     // scene on different streams may overlap (a frame's drain with the next frame's start), launches on one stream are
     // ordered by the stream.  A slot is bound to the stream that used it last; when all are bound to other streams the
@@ -69,18 +67,46 @@ struct Scene {
         void* d_queue = nullptr; void* d_stats = nullptr;
         void* ev_start = nullptr; void* ev_stop = nullptr;
         void* stream = nullptr; bool recorded = false, timed = true; unsigned long long seq = 0;
-    } slots[N_SLOTS];
-    int last_slot = -1;                    // slot of the most recent launch (what rt_last_* report)
+    };
+    // Everything that lives on ONE HIP device: the replicated scene tables (the scene is < 2 MB: every device that renders
+    // a share of the frame holds its own copy), launch scratch, and rt_render_multi's per-device buffers.
+    struct DeviceCtx {
+        int device = -1;
+        DeviceScene<double> dev64;
+        DeviceScene<float> dev32;
+        LaunchSlot slots[N_SLOTS];
+        int last_slot = -1;                // slot of the most recent launch on this device
+        void* stream = nullptr;            // rt_render_multi: this device's stream, tile buffer, and (root only) gather / frame buffers
+        void* d_tiles = nullptr; size_t tiles_bytes = 0;
+        void* d_gather = nullptr; size_t gather_bytes = 0;
+        void* d_frame = nullptr; size_t frame_bytes = 0;
+    };
+    std::vector<DeviceCtx*> ctxs;          // created on first use of a device
+    int last_device = -1;                  // device of the most recent launch (what rt_last_* report)
     unsigned long long launch_seq = 0;
+    // rt_render_multi: RCCL communicators of the last device set (csrc/rt_multi.cpp)
+    std::vector<int> comm_devices; std::vector<void*> comms;
+    double multi_ms[4] = {0, 0, 0, 0};     // last rt_render_multi: slowest device's kernel, gather, un-permute, whole call (wall)
     double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
 
     void invalidate() { flat_valid = false; }
+    DeviceCtx& ctx_for(int device) {
+        for (DeviceCtx* c : ctxs) if (c->device == device) return *c;
+        DeviceCtx* c = new DeviceCtx(); c->device = device; ctxs.push_back(c); return *c;
+    }
+    DeviceCtx* last_ctx() { for (DeviceCtx* c : ctxs) if (c->device == last_device) return c; return nullptr; }
 };
 
 // rt_flatten.cpp
 bool flatten_scene(Scene& s);
+// rt_host.cpp (shared with rt_multi.cpp)
+int set_error(const std::string& m);                              // leaves the message for rt_last_error(); returns -1
+int device_kernel_ms(Scene& s, int device, float* ms);            // duration of the last path-tracing kernel launched on `device`
+void multi_release(Scene& s);                                     // rt_multi.cpp: destroys the cached RCCL communicators
 // camera (src/camera.rs:19-49)
 struct rt_camera_args { double lookfrom[3], lookat[3], vup[3], vfov, aspect, aperture, focus_dist, time0, time1; };
 void camera_new(const rt_camera_args& a, DCamera<double>& out);
 
 } // namespace rt
+
+struct rt_scene { rt::Scene s; };       // the opaque handle of include/rt_amd.h

@@ -4,7 +4,7 @@
 // (same constructor names and argument order).  Usage mirrors `cargo run --release > image.ppm` (README.md:4):
 //
 //     rtrender [--scene cornell|random|final|teapot|two_sphere|two_perlin|earth|light_room|smoke|progress] [--width W] [--height H] [--spp N] [--depth D]
-//              [--seed S] [--obj teapot.obj] [--earth earth.ppm] [--f32] [--fast-bvh] > image.ppm
+//              [--seed S] [--obj teapot.obj] [--earth earth.ppm] [--f32] [--fast-bvh] [--gpus N] > image.ppm
 //
 // The reference hard-codes its settings as consts (main.rs:579-583, :623); they are flags here.
 #include <cstdio>
@@ -218,6 +218,7 @@ int main(int argc, char** argv) {
     SceneKind scene = SceneKind::CornellBox;
     uint32_t image_width = 500, image_height = 500, samples_per_pixel = 800, max_depth = 100;    // main.rs:579-583
     uint64_t seed = 0x5EED; uint32_t flags = RT_F64; bool fast_bvh = false;
+    int gpus = 1;                                                           // --gpus N: the first N devices (0 = all) through rt_render_multi
     std::string obj_path = "teapot.obj", earth_path = "earthmap.jpg";       // the reference's asset names (main.rs:248,491)
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
@@ -238,6 +239,8 @@ int main(int argc, char** argv) {
         else if (a == "--obj") obj_path = next();
         else if (a == "--earth") earth_path = next();
         else if (a == "--f32") flags |= RT_F32;
+        else if (a == "--gpus") gpus = std::atoi(next());
+        else if (a == "--collective") flags |= RT_MULTI_COLLECTIVE;         // with --gpus 1: run the RCCL gather anyway
         else if (a == "--fast-bvh") { fast_bvh = true; flags |= RT_NEAR_FIRST_BVH; }      // opt-in, not the reference's tree / visiting order
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
@@ -306,7 +309,16 @@ int main(int argc, char** argv) {
         }
         }
         // main.rs:772-833: the whole loop nest is this one call
-        std::vector<double> pixel_sums = render(s, camera, background, image_width, image_height, samples_per_pixel, max_depth, seed, flags);
+        std::vector<double> pixel_sums;
+        if (gpus == 1 && !(flags & RT_MULTI_COLLECTIVE)) {
+            pixel_sums = render(s, camera, background, image_width, image_height, samples_per_pixel, max_depth, seed, flags);
+        } else {                                                            // every GPU of the node from this one process
+            if (gpus < 0 || gpus > 32) throw Error("--gpus must be 0 (all) .. 32");
+            const uint32_t mask = gpus == 0 ? 0u : (gpus == 32 ? 0xFFFFFFFFu : ((1u << gpus) - 1u));
+            pixel_sums = render_multi(s, camera, background, image_width, image_height, samples_per_pixel, max_depth, mask, seed, flags);
+            double ms[4]; rt_last_multi_ms(s.raw(), ms);
+            std::fprintf(stderr, "rt_render_multi: slowest kernel %.2f ms, gather %.3f ms, un-permute %.3f ms, call %.2f ms\n", ms[0], ms[1], ms[2], ms[3]);
+        }
         write_ppm("-", pixel_sums, image_width, image_height, samples_per_pixel);              // main.rs:767-769,832
         std::fprintf(stderr, "Done.\n");                                                      // main.rs:835
     } catch (const Error& e) {

@@ -14,6 +14,7 @@ from .api import CameraParams, SceneBuilder
 
 RT_F64, RT_F32, RT_STOP_ON_ZERO, RT_ISOTROPIC_SCATTER, RT_NEAR_FIRST_BVH = 0, 1, 2, 4, 8
 RT_PERSISTENT_BVH, RT_LOCKSTEP_BVH = 16, 32
+RT_MULTI_COLLECTIVE = 64
 FLATTEN_COUNT_NAMES = ("objects", "ops", "rects", "spheres", "moving_spheres", "triangles", "bvh_nodes",
                        "materials", "textures", "lights", "media", "perlins")
 
@@ -80,6 +81,27 @@ def render(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: 
     if rc != 0:
         raise RenderError(_err(be))
     return (out, samples) if want_samples else out
+
+
+def render_multi(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int, device_mask: int = 0,
+                 seed: int = 0x5EED, flags: int = RT_F64, tile_px: int = 0):
+    """The whole frame on the GPUs of this node selected by `device_mask` (bit d = HIP device d; 0 = all visible) from ONE call:
+    per-device replicas of the scene, tiles dealt round-robin, one RCCL gather to the first device, un-permuted there
+    (rt_render_multi, csrc/rt_multi.cpp).  Returns the (H, W, 3) per-pixel sums like render()."""
+    be = _lib.load()
+    out = np.zeros((H, W, 3), dtype=np.float64)
+    bg = (C.c_double * 3)(*[float(x) for x in background])
+    if be.lib.rt_render_multi(b.h, C.byref(cam), bg, W, H, spp, max_depth, seed, flags, device_mask, tile_px, out.ctypes.data) != 0:
+        raise RenderError(_err(be))
+    return out
+
+
+def last_multi_ms(b: SceneBuilder) -> dict:
+    be = _lib.load()
+    ms = (C.c_double * 4)()
+    if be.lib.rt_last_multi_ms(b.h, ms) != 0:
+        raise RenderError(_err(be))
+    return {"slowest_kernel_ms": ms[0], "gather_ms": ms[1], "unpermute_ms": ms[2], "call_ms": ms[3]}
 
 
 def local_tiles(W: int, H: int, tile_px: int, rank: int, world: int) -> int:

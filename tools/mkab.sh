@@ -9,6 +9,6 @@ BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-fu
 /opt/rocm/bin/hipcc $BASE -O2 -mllvm -enable-misched=0 $f1 -DRT_TU=1 -c $src -o ab/${name}_lean.o &
 /opt/rocm/bin/hipcc $BASE $f2 -DRT_TU=2 -c $src -o ab/${name}_rest.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/$name.so ab/${name}_lean.o ab/${name}_rest.o rt_host.o rt_flatten.o rt_jpeg.o rt_obj.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ab/$name.so ab/${name}_lean.o ab/${name}_rest.o rt_host.o rt_multi.o rt_flatten.o rt_jpeg.o rt_obj.o
 rm -f ab/${name}_lean.o ab/${name}_rest.o
 echo built ab/$name.so
