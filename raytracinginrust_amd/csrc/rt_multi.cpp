@@ -14,6 +14,8 @@
 // librt_amd.so carries no link-time dependency on it and single-GPU users never load it.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cstdio>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -134,7 +136,15 @@ int rt_render_multi(rt_scene* sc, const rt_camera* cam, const double bg[3], uint
         if (s.comm_devices != devs) {
             rt::multi_release(s);
             s.comms.assign(N, nullptr);
-            NCCLX(R->CommInitAll(s.comms.data(), (int)N, devs.data()));
+            // RCCL prints a version banner to stdout when it initialises; the reference's contract is "the image IS stdout"
+            // (`cargo run --release > image.ppm`, README.md:4), so stdout points at stderr while the communicators are created
+            std::fflush(stdout);
+            const int saved_out = dup(1);
+            if (saved_out >= 0) (void)dup2(2, 1);
+            const int init_rc = R->CommInitAll(s.comms.data(), (int)N, devs.data());
+            std::fflush(stdout);
+            if (saved_out >= 0) { (void)dup2(saved_out, 1); (void)close(saved_out); }
+            NCCLX(init_rc);
             s.comm_devices = devs;
         }
     }
