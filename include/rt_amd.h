@@ -194,6 +194,9 @@ int rt_kernel_time_total(rt_scene*, double* ms_total, unsigned long long* n_laun
  * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
  * that carried a live path ([2] / (64*[1]) = lane utilisation). */
 int rt_last_stats(rt_scene*, unsigned long long out3[3]);
+/* Geometry of the most recent launch: [0] workgroups, [1] threads per workgroup, [2] dynamic LDS bytes per workgroup, [3] BVH nodes
+ * staged in LDS by each workgroup (the top levels of the trees), [4] BVH nodes in the scene, [5] resident workgroups per CU. */
+int rt_last_launch_info(rt_scene*, uint32_t out6[6]);
 /* Per-pixel accumulator flushes of the most recent finished launch; each is three f64 atomic adds to the frame — the
  * kernel's only global write traffic (used to calibrate the WRITE_SIZE counter). */
 int rt_last_flush_count(rt_scene*, unsigned long long* out);

@@ -130,7 +130,8 @@ struct Flattener {
         }
     }
 
-    // ---- BVH::new, src/bvh.rs:18-73.  Emits nodes in DFS preorder (left child = parent + 1).
+    // ---- BVH::new, src/bvh.rs:18-73.  Emits nodes in DFS preorder (left child = parent + 1); relayout_bvh_by_depth() below then
+    // renumbers them by depth and stores both children.
     // `sort_unstable_by` leaves ties unspecified; a stable sort is used (tie order changes cost, never results).
     bool build_bvh(std::vector<int> items, uint32_t depth, uint32_t& out_index, Box& out_box) {
         if (items.empty()) return fail("no object in the scene");                    // bvh.rs:55
@@ -361,12 +362,49 @@ struct Flattener {
     }
 };
 
+// The kernels stage the first n_cached node ids in LDS, so ids are handed out by depth: every tree's root first, then all the
+// depth-1 nodes, ... (ties in build order).  Traversal order does not depend on ids: an inner node names both its children
+// (c = left, b = right), and a leaf keeps its rank in DFS preorder (c), which is what "later in the reference's visiting order" means
+// for the near-first tie rule.
+void relayout_bvh_by_depth(HostFlat& f) {
+    const size_t n = f.bvh.size();
+    if (n == 0) return;
+    std::vector<uint32_t> depth(n, 0xFFFFFFFFu);
+    std::vector<std::pair<uint32_t, uint32_t>> todo;          // (preorder id, depth)
+    for (const DObject& ob : f.objects) if (ob.geom_kind == G_BVH) todo.push_back({ob.geom_first, 0u});
+    while (!todo.empty()) {
+        const auto [i, d] = todo.back(); todo.pop_back();
+        depth[i] = d;
+        if (!(f.bvh[i].a & BVH_LEAF)) { todo.push_back({f.bvh[i].b, d + 1u}); todo.push_back({i + 1u, d + 1u}); }
+    }
+    std::vector<uint32_t> order(n), new_id(n);
+    for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return depth[x] < depth[y]; });
+    for (size_t k = 0; k < n; k++) new_id[order[k]] = (uint32_t)k;
+    std::vector<DBvhNode<double>> out(n);
+    for (size_t i = 0; i < n; i++) {
+        DBvhNode<double> nd = f.bvh[i];
+        nd.pad = 0;
+        if (nd.a & BVH_LEAF) nd.c = (uint32_t)i;
+        else { nd.c = new_id[i + 1]; nd.b = new_id[nd.b]; }
+        out[new_id[i]] = nd;
+    }
+    f.bvh.swap(out);
+    for (DObject& ob : f.objects) if (ob.geom_kind == G_BVH) ob.geom_first = new_id[ob.geom_first];
+}
+
 } // namespace
 
 bool flatten_scene(Scene& s) {
     if (s.flat_valid) return true;
     Flattener fl(s);
     if (!fl.run()) { s.error = fl.err; return false; }
+    relayout_bvh_by_depth(s.flat);
+    // the NaN-free form of AABB::hit (rt_kernel.hip: box_inside_tame) needs finite boxes with min <= max
+    s.flat.bvh_tame = true;
+    for (const DBvhNode<double>& nd : s.flat.bvh)
+        for (int k = 0; k < 3; k++)
+            if (!(std::fabs(nd.mn[k]) < 1e300 && std::fabs(nd.mx[k]) < 1e300 && nd.mn[k] <= nd.mx[k])) s.flat.bvh_tame = false;
     s.flat_valid = true;
     return true;
 }

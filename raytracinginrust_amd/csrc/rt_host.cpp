@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -353,7 +354,7 @@ template <typename T> void cv(const DSphere<double>& a, DSphere<T>& b) { for (in
 template <typename T> void cv(const DMSphere<double>& a, DMSphere<T>& b) { for (int k = 0; k < 3; k++) { b.c0[k] = (T)a.c0[k]; b.c1[k] = (T)a.c1[k]; } b.t0 = (T)a.t0; b.t1 = (T)a.t1; b.r = (T)a.r; b.mat = a.mat; b.pad = 0; }
 template <typename T> void cv(const DTri<double>& a, DTri<T>& b) { for (int k = 0; k < 3; k++) { b.v0[k] = (T)a.v0[k]; b.e1[k] = (T)a.e1[k]; b.e2[k] = (T)a.e2[k]; } b.mat = a.mat; b.pad = 0; }
 template <typename T> void cv(const DOp<double>& a, DOp<T>& b) { b.kind = a.kind; b.axis = a.axis; b.x = (T)a.x; b.y = (T)a.y; b.z = (T)a.z; }
-template <typename T> void cv(const DBvhNode<double>& a, DBvhNode<T>& b) { for (int k = 0; k < 3; k++) { b.mn[k] = (T)a.mn[k]; b.mx[k] = (T)a.mx[k]; } b.a = a.a; b.b = a.b; }
+template <typename T> void cv(const DBvhNode<double>& a, DBvhNode<T>& b) { for (int k = 0; k < 3; k++) { b.mn[k] = (T)a.mn[k]; b.mx[k] = (T)a.mx[k]; } b.a = a.a; b.b = a.b; b.c = a.c; b.pad = 0; }
 template <typename T> void cv(const DMaterial<double>& a, DMaterial<T>& b) { b.kind = a.kind; b.tex = a.tex; for (int k = 0; k < 3; k++) b.albedo[k] = (T)a.albedo[k]; b.param = (T)a.param; }
 template <typename T> void cv(const DTexture<double>& a, DTexture<T>& b) { b.kind = a.kind; b.a = a.a; b.b = a.b; b.c = a.c; for (int k = 0; k < 3; k++) b.color[k] = (T)a.color[k]; b.scale = (T)a.scale; }
 template <typename T> void cv(const DPbr<double>& a, DPbr<T>& b) {
@@ -459,6 +460,18 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
     return out;
 }
 
+// BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
+// queues and stacks; 0 for the list-scene kernels.
+template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop) {
+    if (!g.one_per_cu || f.bvh.empty()) return 0u;
+    size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor;
+    if (lds_total < 65536u) lds_total = 65536u;
+    const size_t fixed = pathtrace_lds_bytes(g, f.bvh_depth, 0u, sizeof(DBvhNode<T>));
+    if (fixed + sizeof(DBvhNode<T>) > lds_total) return 0u;
+    const size_t room = (lds_total - fixed) / sizeof(DBvhNode<T>);
+    return (uint32_t)std::min(room, f.bvh.size());
+}
+
 template <typename T>
 int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                 uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
@@ -478,6 +491,12 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     P.stack_depth = f.bvh_depth;
+    {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
+        const double big = sizeof(T) == 8 ? 1e300 : 1e30;
+        bool tame = f.bvh_tame;
+        for (const DBvhNode<double>& nd : f.bvh) for (int k = 0; k < 3 && tame; k++) tame = std::fabs(nd.mn[k]) < big && std::fabs(nd.mx[k]) < big;
+        P.bvh_tame = tame ? 1u : 0u;
+    }
     rt_camera_args ca; std::memcpy(&ca, camp, sizeof(ca));
     DCamera<double> cam; camera_new(ca, cam);
     for (int k = 0; k < 3; k++) {
@@ -508,16 +527,19 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.out = (double*)d_out; P.samples_out = (double*)d_samples;
 
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
-    size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * P.stack_depth * 64 * sizeof(uint32_t);
+    const LaunchShape shape = pathtrace_shape(f.feats, P.flags);
+    P.n_cached = cached_nodes<T>(shape, f, prop);
+    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
-    if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
+    if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel (LDS: " + std::to_string(shmem) + " bytes per workgroup)");
+    const uint64_t waves_per_block = shape.threads / 64u;
     uint64_t waves_needed = (n_local_px * spp + 63) / 64;
-    uint64_t blocks_needed = (waves_needed + 3) / 4;
+    uint64_t blocks_needed = (waves_needed + waves_per_block - 1) / waves_per_block;
     uint64_t n_blocks = (uint64_t)prop.multiProcessorCount * (uint64_t)bpc;
     if (n_blocks > blocks_needed) n_blocks = blocks_needed;
     if (n_blocks == 0) n_blocks = 1;
     {   // split only the last ~1.5 pixels per resident wave into fine chunks
-        uint64_t fine_px = n_blocks * 4ull * 3ull / 2ull;
+        uint64_t fine_px = n_blocks * waves_per_block * 3ull / 2ull;
         if (P.chunks_per_px > 1 && n_local_px > fine_px) P.n_coarse_px = (uint32_t)(n_local_px - fine_px);
         uint64_t n_chunks64 = P.chunks_per_px > 1
             ? (uint64_t)P.n_coarse_px + (n_local_px - P.n_coarse_px) * (uint64_t)P.chunks_per_px
@@ -535,6 +557,8 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     slot->recorded = true; slot->timed = false; slot->seq = ++s.launch_seq;
     c.last_slot = (int)(slot - c.slots);
     s.last_device = c.device;
+    s.launch_info[0] = (uint32_t)n_blocks; s.launch_info[1] = shape.threads; s.launch_info[2] = (uint32_t)shmem; s.launch_info[3] = P.n_cached;
+    s.launch_info[4] = (uint32_t)f.bvh.size(); s.launch_info[5] = (uint32_t)bpc;
     return 0;
 }
 
@@ -583,9 +607,12 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
         if (!l.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_start = e; }
         if (!l.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_stop = e; }
     }
-    size_t shmem = RT_REGEN_LDS_BYTES + (size_t)4 * s.flat.bvh_depth * 64 * sizeof(uint32_t);
     const uint32_t eff = effective_flags(s.flat, flags);
-    int bpc = (flags & RT_F32) ? pathtrace_blocks_per_cu<float>(s.flat.feats, eff, shmem) : pathtrace_blocks_per_cu<double>(s.flat.feats, eff, shmem);
+    const LaunchShape shape = pathtrace_shape(s.flat.feats, eff);
+    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, cp->device));
+    int bpc;
+    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<float>(shape, s.flat, prop), sizeof(DBvhNode<float>)));
+    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<double>(shape, s.flat, prop), sizeof(DBvhNode<double>)));
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;
@@ -635,6 +662,13 @@ static int read_stats(rt_scene* sc, unsigned long long h[RT_STATS_SLOTS]) {
     unsigned long long raw[RT_STATS_ROWS * RT_STATS_SLOTS];
     HIP_OK(hipMemcpy(raw, l.d_stats, sizeof(raw), hipMemcpyDeviceToHost));      // unified addressing: the pointer names its device
     for (uint32_t k = 0; k < RT_STATS_SLOTS; k++) { h[k] = 0; for (uint32_t r = 0; r < RT_STATS_ROWS; r++) h[k] += raw[r * RT_STATS_SLOTS + k]; }
+    return 0;
+}
+// Geometry of the most recent launch: [0] workgroups, [1] threads per workgroup, [2] dynamic LDS bytes per workgroup, [3] BVH nodes
+// staged in LDS, [4] BVH nodes in the scene, [5] resident workgroups per CU
+int rt_last_launch_info(rt_scene* sc, uint32_t out6[6]) {
+    if (!sc || !out6) return set_err("null argument");
+    for (int k = 0; k < 6; k++) out6[k] = sc->s.launch_info[k];
     return 0;
 }
 int rt_last_stats(rt_scene* sc, unsigned long long out[3]) {

@@ -8,8 +8,9 @@
 //   object = wrapper chain ops[first_op .. first_op+n_ops) outermost first (Translate / Rotate / FlipNormal),
 //            optional ConstantMedium (outermost only), and one geometry:
 //              a typed range of primitives (1 rect, 6 rects = Cube, n triangles = Mesh list, ...) or a BVH root
-//   BVH    = nodes in DFS preorder: left child = node + 1, right child + split axis stored; leaves hold a typed
-//            primitive range (a sphere, a moving sphere, a triangle, or a Cube's 6 rects)
+//   BVH    = nodes of all the scene's trees ordered by depth (roots first), both children stored: the first `n_cached` ids — the top
+//            levels, where most visits go — are staged in LDS by each workgroup, the rest are fetched per lane; leaves hold a typed
+//            primitive range (a sphere, a moving sphere, a triangle, or a Cube's 6 rects) and their rank in DFS preorder
 //   lights = light records (rect / sphere / "other" = trait default pdf 0, random (1,0,0))
 //
 // Records are templated on the arithmetic type: the f64 build is the reference-precision product path,
@@ -44,8 +45,9 @@ enum Feat : uint32_t {
     F_PERSIST = 1u << 8     // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
 };
 
-static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count;
-                                                   // inner: node.a = split axis (0..2), node.b = right child, left child = node + 1
+static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count, node.c = rank in DFS
+                                                   //       preorder (= the reference's visiting order: resolves exact-t ties in near-first mode);
+                                                   // inner: node.a = split axis (0..2), node.b = right child, node.c = left child
 static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
 static const int RT_MAX_BVH_DEPTH = 48;
 
@@ -57,7 +59,7 @@ template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; u
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct DOp { uint32_t kind, axis; T x, y, z; };                         // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
 struct DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
-template <typename T> struct alignas(8 * sizeof(T)) DBvhNode { T mn[3], mx[3]; uint32_t a, b; };     // f64: 64 B = one line per fetch; f32: 32 B
+template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, pad; };       // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 template <typename T> struct DMaterial { uint32_t kind, tex; T albedo[3]; T param; };         // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
 template <typename T> struct DTexture { uint32_t kind, a, b, c; T color[3]; T scale; };       // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height
@@ -86,6 +88,9 @@ template <typename T> struct KParams {
     const DPbr<T>* pbr;
     const uint8_t* image_bytes;
     uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS
+    uint32_t n_cached;             // BVH nodes [0, n_cached) are copied into LDS by every workgroup at launch (depth order: the top levels)
+    uint32_t bvh_tame;             // every BVH box is finite, below 1e300 in magnitude and has min <= max: rays that are tame too may
+                                   // take the NaN-free form of AABB::hit (rt_kernel.hip: box_inside_tame) — same answers
     // frame
     DCamera<T> cam;
     T background[3];

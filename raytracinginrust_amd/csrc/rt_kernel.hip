@@ -332,12 +332,71 @@ template <typename T> DEV bool bvh_accept(bool near_first, T t, T closest, uint3
     return !near_first || t < closest || !(t == closest) || leaf >= best_leaf;
 }
 
+// AABB::hit, aabb.rs:19-36, for one node.  `inv` is 1/d (aabb.rs:21 recomputes it per node; same value every time).
+// EXACT form: per axis t0 = (min - o) * inv, t1 = (max - o) * inv, swapped when inv < 0, t_in = t0.max(t_in), t_out = t1.min(t_out)
+// (f64::max / min ignore a NaN operand), miss as soon as t_out <= t_in.
+// TAME form (same answer, fewer instructions), used when no NaN can arise and every box has min <= max:
+//   * min <= max and monotonic rounding give (min - o) <= (max - o), so t0 <= t1 for inv > 0 and t0 >= t1 for inv < 0: the swapped
+//     pair is (min(t0, t1), max(t0, t1));
+//   * t_in only grows and t_out only shrinks along the axes, so "t_out <= t_in at some axis" is "t_out <= t_in after the last";
+//   * without NaNs !(t_out <= t_in) is t_out > t_in.
+// No NaN arises when o and inv are finite and |o|, |box| < 1e300 (no inf - inf, no 0 * inf); a ray with a zero direction component
+// (inv = inf) or a scene with an inverted / non-finite box takes the exact form (ray_is_tame, KParams::bvh_tame).
+template <typename T> DEV bool box_inside_exact(const DBvhNode<T>& nd, V3<T> o, V3<T> inv, T t_min, T closest) {
+    bool inside = true;
+    T t_in = t_min, t_o = closest;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        T inv_d = a == 0 ? inv.x : (a == 1 ? inv.y : inv.z);
+        T org = a == 0 ? o.x : (a == 1 ? o.y : o.z);
+        T t0 = (nd.mn[a] - org) * inv_d;
+        T t1 = (nd.mx[a] - org) * inv_d;
+        if (inv_d < T(0)) { T tmp = t0; t0 = t1; t1 = tmp; }
+        t_in = m_max(t_in, t0);
+        t_o = m_min(t_o, t1);
+        if (t_o <= t_in) inside = false;    // aabb.rs:31-33 returns here; later axes cannot un-fail it
+    }
+    return inside;
+}
+// min / max of two numbers known not to be NaN: the bare instruction (fmin / fmax would first quiet each operand with a v_max x, x)
+DEV double min_nn(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV double max_nn(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float min_nn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float max_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <typename T> DEV bool box_inside_tame(const DBvhNode<T>& nd, V3<T> o, V3<T> inv, T t_min, T closest) {
+    const T ax = (nd.mn[0] - o.x) * inv.x, bx = (nd.mx[0] - o.x) * inv.x;
+    const T ay = (nd.mn[1] - o.y) * inv.y, by = (nd.mx[1] - o.y) * inv.y;
+    const T az = (nd.mn[2] - o.z) * inv.z, bz = (nd.mx[2] - o.z) * inv.z;
+    const T t_in = max_nn(max_nn(max_nn(min_nn(ax, bx), t_min), min_nn(ay, by)), min_nn(az, bz));
+    const T t_o = min_nn(min_nn(min_nn(max_nn(ax, bx), closest), max_nn(ay, by)), max_nn(az, bz));
+    return t_o > t_in;
+}
+template <typename T> DEV bool finite_(T x) { return x - x == T(0); }
+template <typename T> DEV bool ray_is_tame(V3<T> o, V3<T> inv) {
+    const T big = T(sizeof(T) == 8 ? 1e300 : 1e30);
+    return finite_(inv.x) && finite_(inv.y) && finite_(inv.z) && m_abs(o.x) < big && m_abs(o.y) < big && m_abs(o.z) < big;
+}
+// one BVH node through the constant address space with a 32-bit byte offset (scalar base + per-lane offset addressing)
+template <typename T> DEV DBvhNode<T> ld_node_at(const DBvhNode<T>* base, uint32_t node) {
+    return ld_record((const DBvhNode<T>*)((const char*)base + (size_t)(node * (uint32_t)sizeof(DBvhNode<T>))));
+}
+// The workgroup's dynamic LDS.  Layout (pathtrace_kernel): [n_cached BVH nodes][per wave: camera-path queue][per wave: BVH stack].
+extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+// A traversal step's node.  Incoherent rays make every lane fetch a different 64-byte node: per-lane vector loads of that shape
+// are what bounds the traversal (*measured*, round 2: doubling the node loads — same cache lines — cost the random-spheres frame
+// +64 %, while removing a fifth of the box test's arithmetic gained 2 %).  Node ids are handed out by depth (rt_flatten.cpp), so
+// the ids below n_cached are the top levels of every tree, where most visits go: each workgroup holds them in LDS (one copy per
+// CU: the BVH kernels run one workgroup per CU) and a visit there is four ds_read_b128 instead of four global loads.
+template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t node) {
+    if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * (uint32_t)sizeof(DBvhNode<T>));
+    return ld_node_at(P.bvh, node);
+}
+
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
     V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
     T closest = t_max;
     bool any = false;
-    const uint32_t DONE = 0xFFFFFFFFu;
     uint32_t node = root;
     uint32_t sp = 0;
     const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;   // RT_NEAR_FIRST_BVH (opt-in), compile-time: no cost in the default mode
@@ -351,35 +410,23 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     // walking, or nobody can step; then the pending leaves are tested together.
     uint32_t leaf_a = 0, leaf_b = 0, leaf_node = 0;
     bool have_leaf = false;
+    const uint32_t DONE = 0xFFFFFFFFu;
+    const bool tame = P.bvh_tame != 0u && __ballot(!ray_is_tame(ray.o, inv)) == 0ull;   // wave-uniform: every lane of this search
     for (;;) {
         for (;;) {
             const bool want_box = node != DONE && !have_leaf;
             const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
             if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
             if (want_box) {
-                const DBvhNode<T> nd = ld_node(P.bvh + node);
-                bool inside = true;
-                {
-                    T t_in = t_min, t_o = closest;
-#pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        T inv_d = a == 0 ? inv.x : (a == 1 ? inv.y : inv.z);
-                        T org = a == 0 ? ray.o.x : (a == 1 ? ray.o.y : ray.o.z);
-                        T t0 = (nd.mn[a] - org) * inv_d;
-                        T t1 = (nd.mx[a] - org) * inv_d;
-                        if (inv_d < T(0)) { T tmp = t0; t0 = t1; t1 = tmp; }
-                        t_in = m_max(t_in, t0);
-                        t_o = m_min(t_o, t1);
-                        if (t_o <= t_in) inside = false;    // aabb.rs:31-33 returns here; later axes cannot un-fail it
-                    }
-                }
+                const DBvhNode<T> nd = fetch_node(P, node);
+                const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, closest) : box_inside_exact(nd, ray.o, inv, t_min, closest);
                 if (inside && !(nd.a & BVH_LEAF)) {
                     const bool right_first = near_first && get(ray.d, nd.a) < T(0);
-                    stack[sp * 64u] = right_first ? node + 1u : nd.b;      // the other child waits (reference order: right waits)
+                    stack[sp * 64u] = right_first ? nd.c : nd.b;           // the other child waits (reference order: right waits)
                     sp++;
-                    node = right_first ? nd.b : node + 1u;
+                    node = right_first ? nd.b : nd.c;
                 } else {
-                    if (inside) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; leaf_node = node; }
+                    if (inside) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; leaf_node = nd.c; }
                     if (sp == 0) node = DONE;
                     else { sp--; node = stack[sp * 64u]; }
                 }
@@ -823,6 +870,18 @@ template <typename T> DEV V3<T> brdf_pdf_generate(const DPbr<T>& m, const Onb<T>
     return onb_local(uvw, reflect_(r_in, wh));
 }
 
+// ------------------------------------------------------------------ launch geometry per kernel family
+// List scenes: 256-thread workgroups, several per CU.  BVH scenes: ONE workgroup per CU holding every wave the register budget
+// allows (4 per SIMD = 1024 threads; 3 = 768 for the persistent-traversal and the principled-material kernels), so that the CU's
+// 160 KB of LDS holds one copy of the top of the BVH beside the waves' stacks and queues.
+template <uint32_t FEATS> struct Shape {
+    static constexpr uint32_t WAVES_PER_SIMD = FEATS == 0u ? RT_WAVES_LEAN : ((FEATS & F_PBR) ? RT_WAVES_PBR : ((FEATS & F_PERSIST) ? RT_WAVES_PERSIST : RT_WAVES_BVH));
+    static constexpr bool ONE_PER_CU = (FEATS & F_BVH) != 0u;
+    static constexpr uint32_t WAVES = ONE_PER_CU ? 4u * WAVES_PER_SIMD : 4u;
+    static constexpr uint32_t THREADS = 64u * WAVES;
+    static constexpr uint32_t QN = ONE_PER_CU ? 16u : 64u;
+};
+
 // ------------------------------------------------------------------ wave helpers
 DEV uint32_t lane_rank(unsigned long long mask) {   // number of set bits of `mask` below this lane
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -856,7 +915,9 @@ DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out,
 }
 
 // ------------------------------------------------------------------ wave-uniform work cursor + regeneration queue
-static const uint32_t REGEN_BYTES = 7u * 64u * 8u + 6u * 64u * 4u;      // per-wave regeneration queue (sized for f64), 5120 B
+// per-wave regeneration queue of QN camera paths (sized for f64): 80 B per entry.  List scenes generate 64 at a time (every lane
+// busy: the camera code is 6 % of their bounce); BVH scenes, where it is noise, keep 16 so that LDS goes to BVH nodes instead.
+static constexpr uint32_t regen_bytes(uint32_t qn) { return 7u * qn * 8u + 6u * qn * 4u; }
 static const uint32_t NONE_PX = 0xFFFFFFFFu;
 // RT_DIAG (diagnostic build only, never shipped): per-section wave-cycle shares via s_memtime, written to stats[3..8].
 #ifdef RT_DIAG
@@ -905,13 +966,13 @@ template <typename T> DEV void take_chunk(const KParams<T>& P, WaveWork& w, uint
 }
 // Refill the queue: the next (up to) 64 samples of the cursor, all lanes generating (main.rs:813-820).  False when the
 // global work queue is exhausted and nothing was generated.
-template <typename T>
+template <typename T, uint32_t QN>
 DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32) {
     const uint32_t n_px = P.W * P.H;
     bool have = false;
     uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
     uint32_t n_gen = 0;
-    while (n_gen < 64u) {
+    while (n_gen < QN) {
         if (w.cur_px == w.end_px) {
             uint32_t c = 0;
             if (lane == 0) c = atomicAdd(P.queue, 1u);
@@ -921,7 +982,7 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
         }
         if (w.cur_gp >= n_px || w.s_lo >= w.s_hi) { w.cur_px++; w.cur_s = w.s_lo; if (w.cur_px != w.end_px) locate(P, w); continue; }   // padding pixel / empty range
         uint32_t avail = w.s_hi - w.cur_s;
-        uint32_t room = 64u - n_gen;
+        uint32_t room = QN - n_gen;
         uint32_t take = room < avail ? room : avail;
         if (lane >= n_gen && lane < n_gen + take) { have = true; g_px = w.cur_px; g_s = w.cur_s + (lane - n_gen); g_gp = w.cur_gp; g_i = w.cur_i; g_j = w.cur_j; }
         n_gen += take;
@@ -948,11 +1009,11 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
         T time = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
         V3<T> go = ld3(P.cam.origin) + offset;
         V3<T> gd = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
-        q_real[0u * 64u + lane] = go.x; q_real[1u * 64u + lane] = go.y; q_real[2u * 64u + lane] = go.z;
-        q_real[3u * 64u + lane] = gd.x; q_real[4u * 64u + lane] = gd.y; q_real[5u * 64u + lane] = gd.z;
-        q_real[6u * 64u + lane] = time;
-        q_u32[0u * 64u + lane] = g.s0; q_u32[1u * 64u + lane] = g.s1; q_u32[2u * 64u + lane] = g.s2; q_u32[3u * 64u + lane] = g.s3;
-        q_u32[4u * 64u + lane] = g_px; q_u32[5u * 64u + lane] = g_s;
+        q_real[0u * QN + lane] = go.x; q_real[1u * QN + lane] = go.y; q_real[2u * QN + lane] = go.z;
+        q_real[3u * QN + lane] = gd.x; q_real[4u * QN + lane] = gd.y; q_real[5u * QN + lane] = gd.z;
+        q_real[6u * QN + lane] = time;
+        q_u32[0u * QN + lane] = g.s0; q_u32[1u * QN + lane] = g.s1; q_u32[2u * QN + lane] = g.s2; q_u32[3u * QN + lane] = g.s3;
+        q_u32[4u * QN + lane] = g_px; q_u32[5u * QN + lane] = g_s;
     }
     w.q_head = 0; w.q_count = n_gen;
     __builtin_amdgcn_wave_barrier();          // one wave: LDS writes above are ordered before the reads below
@@ -960,7 +1021,7 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
 }
 // Lanes with `dead` set take the next camera path from the wave's queue ("compaction by regeneration").  True for the
 // lanes that got one (ray, rng, new_px, path_s are then the new path's).
-template <typename T>
+template <typename T, uint32_t QN>
 DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32, bool dead,
                         RayT<T>& ray, Rng& rng, uint32_t& new_px, uint32_t& path_s) {
     bool got_new = false;
@@ -969,7 +1030,7 @@ DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_re
         if (want == 0) break;
         if (w.q_count == 0) {
             if (w.queue_done) break;
-            if (!refill_queue(P, w, lane, q_real, q_u32)) break;
+            if (!refill_queue<T, QN>(P, w, lane, q_real, q_u32)) break;
         }
         uint32_t n_want = (uint32_t)__popcll(want);
         uint32_t take = n_want < w.q_count ? n_want : w.q_count;
@@ -977,11 +1038,11 @@ DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_re
         if (dead && !got_new && rank < take) {
             const uint32_t e = w.q_head + rank;
             got_new = true;
-            ray.o = mk<T>(q_real[0u * 64u + e], q_real[1u * 64u + e], q_real[2u * 64u + e]);
-            ray.d = mk<T>(q_real[3u * 64u + e], q_real[4u * 64u + e], q_real[5u * 64u + e]);
-            ray.tm = q_real[6u * 64u + e];
-            rng.s0 = q_u32[0u * 64u + e]; rng.s1 = q_u32[1u * 64u + e]; rng.s2 = q_u32[2u * 64u + e]; rng.s3 = q_u32[3u * 64u + e];
-            new_px = q_u32[4u * 64u + e]; path_s = q_u32[5u * 64u + e];
+            ray.o = mk<T>(q_real[0u * QN + e], q_real[1u * QN + e], q_real[2u * QN + e]);
+            ray.d = mk<T>(q_real[3u * QN + e], q_real[4u * QN + e], q_real[5u * QN + e]);
+            ray.tm = q_real[6u * QN + e];
+            rng.s0 = q_u32[0u * QN + e]; rng.s1 = q_u32[1u * QN + e]; rng.s2 = q_u32[2u * QN + e]; rng.s3 = q_u32[3u * QN + e];
+            new_px = q_u32[4u * QN + e]; path_s = q_u32[5u * QN + e];
         }
         w.q_head += take; w.q_count -= take;
     }
@@ -1139,7 +1200,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_T0();
         // ---- lanes whose path has ended take the next camera path from the wave's queue
         uint32_t new_px = 0;
-        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
+        const bool got_new = take_new_paths<T, Shape<FEATS>::QN>(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
         if (__ballot(alive || got_new) == 0) break;     // queue empty and every path finished
         DIAG_ADD(0);
 
@@ -1257,6 +1318,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             }
             const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);      // AABB::hit's 1/d (aabb.rs:21), same value at every node
             const T t_min = TMin<T>::v();
+            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !ray_is_tame(r.o, inv)) == 0ull;   // wave-uniform, this pass
             uint32_t stop_below = n_bvh * 3u / 4u;                  // entered below trav_hi (nothing else to do): until a quarter has finished
             if (stop_below > P.trav_lo) stop_below = P.trav_lo;
             if (stop_below < 1u) stop_below = 1u;
@@ -1276,29 +1338,15 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 if (n_box != 0u && n_leaf * 64u < P.trav_leaf * n) {
                     if (want_box) {
                         n_step_lanes++;
-                        const DBvhNode<T> nd = ld_node(P.bvh + tv_node);
-                        bool inside = true;
-                        {
-                            T t_in = t_min, t_o = tv_closest;
-#pragma unroll
-                            for (int a = 0; a < 3; a++) {
-                                T inv_d = a == 0 ? inv.x : (a == 1 ? inv.y : inv.z);
-                                T org = a == 0 ? r.o.x : (a == 1 ? r.o.y : r.o.z);
-                                T t0 = (nd.mn[a] - org) * inv_d;
-                                T t1 = (nd.mx[a] - org) * inv_d;
-                                if (inv_d < T(0)) { T tmp = t0; t0 = t1; t1 = tmp; }
-                                t_in = m_max(t_in, t0);
-                                t_o = m_min(t_o, t1);
-                                if (t_o <= t_in) inside = false;    // aabb.rs:31-33 returns here; later axes cannot un-fail it
-                            }
-                        }
+                        const DBvhNode<T> nd = fetch_node(P, tv_node);
+                        const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
                         if (inside && !(nd.a & BVH_LEAF)) {
                             const bool right_first = near_first && get(r.d, nd.a) < T(0);
-                            stack[tv_sp * 64u] = right_first ? tv_node + 1u : nd.b;      // the other child waits (reference order: right waits)
+                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;              // the other child waits (reference order: right waits)
                             tv_sp++;
-                            tv_node = right_first ? nd.b : tv_node + 1u;
+                            tv_node = right_first ? nd.b : nd.c;
                         } else {
-                            if (inside) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = tv_node; }
+                            if (inside) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = nd.c; }
                             // this node is finished (culled, or a leaf now pending): the next one comes off the stack
                             if (tv_sp == 0u) tv_node = BVH_DONE;
                             else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
@@ -1348,7 +1396,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         }
         // ---- lanes whose path has ended take the next camera path from the wave's queue
         uint32_t new_px = 0;
-        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
+        const bool got_new = take_new_paths<T, Shape<FEATS>::QN>(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
         // ---- lanes moving on to another pixel hand in their partial sum
         flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
         if (got_new) {
@@ -1395,30 +1443,48 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
 
 // ------------------------------------------------------------------ the kernel
 template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(256, (FEATS == 0u ? RT_WAVES_LEAN : ((FEATS & F_PBR) ? RT_WAVES_PBR : ((FEATS & F_PERSIST) ? RT_WAVES_PERSIST : RT_WAVES_BVH)))) pathtrace_kernel(const KParams<T> P) {
-    // dynamic LDS: [4 waves][REGEN_BYTES] regeneration queues, then [4 waves][stack_depth][64] BVH stacks
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+__global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER_SIMD) pathtrace_kernel(const KParams<T> P) {
+    // dynamic LDS: [n_cached BVH nodes] [WAVES][regen_bytes(QN)] camera-path queues [WAVES][stack_depth][64] BVH stacks
+    typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    unsigned char* regen = lds_raw + wave_in_block * REGEN_BYTES;
-    T* q_real = (T*)regen;                                         // [7][64]: o.x o.y o.z d.x d.y d.z time
-    uint32_t* q_u32 = (uint32_t*)(regen + 7u * 64u * sizeof(T));   // [6][64]: rng s0..s3, local pixel, sample
-    uint32_t* stack = (uint32_t*)(lds_raw + 4u * REGEN_BYTES) + wave_in_block * (P.stack_depth * 64u) + lane;
+    const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
+    if ((FEATS & F_BVH) && P.n_cached != 0u) {
+        // the top of the BVH, once per workgroup: 16-byte pieces, consecutive threads consecutive pieces; the only barrier of the kernel
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4* src = (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
+        for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
+    unsigned char* regen = lds_raw + nodes_bytes + wave_in_block * regen_bytes(S::QN);
+    T* q_real = (T*)regen;                                         // [7][QN]: o.x o.y o.z d.x d.y d.z time
+    uint32_t* q_u32 = (uint32_t*)(regen + 7u * S::QN * sizeof(T)); // [6][QN]: rng s0..s3, local pixel, sample
+    uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(S::QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
     if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack);
     else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack);
 }
 
 // ------------------------------------------------------------------ launch
 template <typename T, uint32_t FEATS>
+static hipError_t allow_lds(size_t shmem) {            // more than the default 64 KB of dynamic LDS needs to be asked for
+    if (shmem <= 65536u) return hipSuccess;
+    return hipFuncSetAttribute((const void*)pathtrace_kernel<T, FEATS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+}
+template <typename T, uint32_t FEATS>
 static hipError_t launch_one(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
-    hipLaunchKernelGGL((pathtrace_kernel<T, FEATS>), dim3(n_blocks), dim3(256), shmem, stream, P);
+    hipError_t e = allow_lds<T, FEATS>(shmem);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((pathtrace_kernel<T, FEATS>), dim3(n_blocks), dim3(Shape<FEATS>::THREADS), shmem, stream, P);
     return hipGetLastError();
 }
 template <typename T, uint32_t FEATS>
 static int occupancy_one(size_t shmem) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pathtrace_kernel<T, FEATS>, 256, shmem) != hipSuccess) return 0;
+    if (allow_lds<T, FEATS>(shmem) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pathtrace_kernel<T, FEATS>, (int)Shape<FEATS>::THREADS, shmem) != hipSuccess) return 0;
+    if (Shape<FEATS>::ONE_PER_CU && nb > 1) nb = 1;       // the register budget is set for exactly one such workgroup per CU
     return nb;
 }
+template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; return g; }
 
 // Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
 // Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
@@ -1431,6 +1497,7 @@ static const uint32_t FEATS_LEAN = 0u;
 // lean kernels: their own translation unit in the product build
 template <typename T> hipError_t launch_lean(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream);
 template <typename T> int occupancy_lean(size_t shmem);
+static LaunchShape shape_lean() { return shape_one<FEATS_LEAN>(); }
 #if RT_TU != 2
 template <typename T> hipError_t launch_lean(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream) { return launch_one<T, FEATS_LEAN>(P, n_blocks, shmem, stream); }
 template <typename T> int occupancy_lean(size_t shmem) { return occupancy_one<T, FEATS_LEAN>(shmem); }
@@ -1464,6 +1531,9 @@ template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t 
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem) {
     return dispatch<T>(scene_feats, flags, [&]() { return occupancy_lean<T>(shmem); },
                        [&](auto feats) { return occupancy_one<T, decltype(feats)::value>(shmem); });
+}
+LaunchShape pathtrace_shape(uint32_t scene_feats, uint32_t flags) {
+    return dispatch<double>(scene_feats, flags, [&]() { return shape_lean(); }, [&](auto feats) { return shape_one<decltype(feats)::value>(); });
 }
 
 template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);

@@ -34,6 +34,7 @@ struct HostFlat {             // canonical f64 flattening
     std::vector<DLight> lights;
     uint32_t feats = 0;
     uint32_t bvh_depth = 0;
+    bool bvh_tame = true;          // all BVH boxes finite, |.| < 1e300 (1e30 matters for the f32 variant: checked there too), min <= max
 };
 
 template <typename T> struct DeviceScene {   // device copies of HostFlat for one arithmetic type
@@ -84,6 +85,7 @@ struct Scene {
     std::vector<DeviceCtx*> ctxs;          // created on first use of a device
     int last_device = -1;                  // device of the most recent launch (what rt_last_* report)
     unsigned long long launch_seq = 0;
+    uint32_t launch_info[6] = {0, 0, 0, 0, 0, 0};      // rt_last_launch_info
     // rt_render_multi: RCCL communicators of the last device set (csrc/rt_multi.cpp)
     std::vector<int> comm_devices; std::vector<void*> comms;
     double multi_ms[4] = {0, 0, 0, 0};     // last rt_render_multi: slowest device's kernel, gather, un-permute, whole call (wall)

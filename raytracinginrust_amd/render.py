@@ -147,6 +147,16 @@ def last_traversal_stats(b: SceneBuilder) -> dict:
     return {"advance_passes": out[0], "advance_lanes": out[1], "traversal_steps": out[2], "traversal_lanes": out[3]}
 
 
+def last_launch_info(b: SceneBuilder) -> dict:
+    """Geometry of the most recent launch (workgroups, threads, LDS bytes, BVH nodes staged in LDS / in the scene, workgroups per CU)."""
+    be = _lib.load()
+    out = (C.c_uint32 * 6)()
+    be.lib.rt_last_launch_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+    if be.lib.rt_last_launch_info(b.h, out) != 0:
+        raise RenderError(_err(be))
+    return dict(zip(("workgroups", "threads", "lds_bytes", "bvh_nodes_in_lds", "bvh_nodes", "workgroups_per_cu"), [int(x) for x in out]))
+
+
 def last_kernel_ms(b: SceneBuilder) -> float:
     be = _lib.load()
     ms = C.c_float()

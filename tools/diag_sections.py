@@ -1,8 +1,8 @@
-"""Section shares of the lock-step kernel from a -DRT_DIAG build (tools/mkvariant.sh diag -DRT_DIAG); shares only, never a timing.
+"""Section shares of the lock-step kernel from a -DRT_DIAG build (tools/mkab.sh diag ... -DRT_DIAG); shares only, never a timing.
 usage: RT_WORKLOADS=C2,C3,C1 python tools/diag_sections.py [spp]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/variants/diag.so')
+os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/ab/diag.so')
 import torch
 from PIL import Image
 from raytracinginrust_amd import _lib, render as R, scenes, workloads
