@@ -527,8 +527,14 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.out = (double*)d_out; P.samples_out = (double*)d_samples;
 
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
-    const LaunchShape shape = pathtrace_shape(f.feats, P.flags);
+    LaunchShape shape = pathtrace_shape(f.feats, P.flags);
     P.n_cached = cached_nodes<T>(shape, f, prop);
+    // the camera-path queue: the kernel family's minimum, widened (refills at full lane occupancy) while every node still fits
+    for (uint32_t q = 64u; q > shape.queue_entries; q >>= 1) {
+        LaunchShape wide = shape; wide.queue_entries = q;
+        if (cached_nodes<T>(wide, f, prop) == P.n_cached) { shape = wide; break; }
+    }
+    P.queue_entries = shape.queue_entries;
     size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel (LDS: " + std::to_string(shmem) + " bytes per workgroup)");

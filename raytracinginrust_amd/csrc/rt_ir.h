@@ -57,12 +57,12 @@ template <typename T> struct alignas(16) DRect { T a0, a1, b0, b1, k; uint32_t p
 template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad; };                       // src/sphere.rs:38-43
 template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
-template <typename T> struct DOp { uint32_t kind, axis; T x, y, z; };                         // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
-struct DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
+template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
+struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, pad; };       // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
-template <typename T> struct DMaterial { uint32_t kind, tex; T albedo[3]; T param; };         // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
+template <typename T> struct alignas(16) DMaterial { uint32_t kind, tex; T albedo[3]; T param; };   // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
-template <typename T> struct DTexture { uint32_t kind, a, b, c; T color[3]; T scale; };       // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height
+template <typename T> struct alignas(16) DTexture { uint32_t kind, a, b, c; T color[3]; T scale; }; // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height
 template <typename T> struct DMedium { T neg_inv_density; uint32_t mat, pad; };               // -(1.0/density), src/medium.rs:42
 struct DLight { uint32_t kind, index; };
 template <typename T> struct DPerlin { T rd_vec[256 * 3]; uint8_t perm_x[256], perm_y[256], perm_z[256]; };   // src/perlin.rs:59-65
@@ -88,6 +88,7 @@ template <typename T> struct KParams {
     const DPbr<T>* pbr;
     const uint8_t* image_bytes;
     uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS
+    uint32_t queue_entries;        // camera paths each wave's LDS queue holds (16, 32 or 64; 80 B each)
     uint32_t n_cached;             // BVH nodes [0, n_cached) are copied into LDS by every workgroup at launch (depth order: the top levels)
     uint32_t bvh_tame;             // every BVH box is finite, below 1e300 in magnitude and has min <= max: rays that are tame too may
                                    // take the NaN-free form of AABB::hit (rt_kernel.hip: box_inside_tame) — same answers

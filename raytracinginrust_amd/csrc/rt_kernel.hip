@@ -135,16 +135,18 @@ template <typename R> DEV R ld_record(const R* p) {
     if (off + 4 <= N) { *(uint32_t*)(dst + off) = *(const CAS uint32_t*)(src + off); }
     return r;
 }
-template <typename T> DEV DRect<T> ld_rect(const DRect<T>* p) { DRect<T> r; r.a0 = cl(&p->a0); r.a1 = cl(&p->a1); r.b0 = cl(&p->b0); r.b1 = cl(&p->b1); r.k = cl(&p->k); r.plane = cl(&p->plane); r.mat = cl(&p->mat); return r; }
+// (whole-record fetches: a wave-uniform index gives a few s_load_dwordx4, a per-lane one — BVH leaves, the hit record, the material
+// — a few global_load_dwordx4 instead of one vector load per field: per-lane vector loads are what the BVH kernels are short of)
+template <typename T> DEV DRect<T> ld_rect(const DRect<T>* p) { return ld_record(p); }
 template <typename T> DEV DSphere<T> ld_sphere(const DSphere<T>* p) { return ld_record(p); }
 template <typename T> DEV DMSphere<T> ld_msphere(const DMSphere<T>* p) { return ld_record(p); }
 template <typename T> DEV DTri<T> ld_tri(const DTri<T>* p) { return ld_record(p); }
-template <typename T> DEV DOp<T> ld_op(const DOp<T>* p) { DOp<T> r; r.kind = cl(&p->kind); r.axis = cl(&p->axis); r.x = cl(&p->x); r.y = cl(&p->y); r.z = cl(&p->z); return r; }
-DEV DObject ld_obj(const DObject* p) { DObject r; r.geom_kind = cl(&p->geom_kind); r.geom_first = cl(&p->geom_first); r.geom_count = cl(&p->geom_count); r.first_op = cl(&p->first_op); r.n_ops = cl(&p->n_ops); r.medium = cl(&p->medium); r.pad0 = r.pad1 = 0; return r; }
+template <typename T> DEV DOp<T> ld_op(const DOp<T>* p) { return ld_record(p); }
+DEV DObject ld_obj(const DObject* p) { return ld_record(p); }
 template <typename T> DEV DBvhNode<T> ld_node(const DBvhNode<T>* p) { return ld_record(p); }
-template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r; r.kind = cl(&p->kind) & MAT_KIND_MASK; r.tex = cl(&p->tex); for (int k = 0; k < 3; k++) r.albedo[k] = cl(&p->albedo[k]); r.param = cl(&p->param); return r; }
+template <typename T> DEV DMaterial<T> ld_mat(const DMaterial<T>* p) { DMaterial<T> r = ld_record(p); r.kind &= MAT_KIND_MASK; return r; }
 template <typename T> DEV DPbr<T> ld_pbr(const DPbr<T>* p) { DPbr<T> r; r.metallic = cl(&p->metallic); r.subsurface = cl(&p->subsurface); r.specular = cl(&p->specular); r.roughness = cl(&p->roughness); r.specular_tint = cl(&p->specular_tint); r.anisotropic = cl(&p->anisotropic); r.sheen = cl(&p->sheen); r.sheen_tint = cl(&p->sheen_tint); r.clearcoat = cl(&p->clearcoat); r.clearcoat_gloss = cl(&p->clearcoat_gloss); return r; }
-template <typename T> DEV DTexture<T> ld_tex(const DTexture<T>* p) { DTexture<T> r; r.kind = cl(&p->kind); r.a = cl(&p->a); r.b = cl(&p->b); r.c = cl(&p->c); for (int k = 0; k < 3; k++) r.color[k] = cl(&p->color[k]); r.scale = cl(&p->scale); return r; }
+template <typename T> DEV DTexture<T> ld_tex(const DTexture<T>* p) { return ld_record(p); }
 DEV DLight ld_light(const DLight* p) { DLight r; r.kind = cl(&p->kind); r.index = cl(&p->index); return r; }
 
 DEV double m_sin(double x) { return ::sin(x); }   DEV float m_sin(float x) { return ::sinf(x); }
@@ -879,7 +881,7 @@ template <uint32_t FEATS> struct Shape {
     static constexpr bool ONE_PER_CU = (FEATS & F_BVH) != 0u;
     static constexpr uint32_t WAVES = ONE_PER_CU ? 4u * WAVES_PER_SIMD : 4u;
     static constexpr uint32_t THREADS = 64u * WAVES;
-    static constexpr uint32_t QN = ONE_PER_CU ? 16u : 64u;
+    static constexpr uint32_t QN_MIN = ONE_PER_CU ? 16u : 64u;    // camera-path queue entries per wave: at least this, up to 64 (KParams::queue_entries)
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -966,8 +968,9 @@ template <typename T> DEV void take_chunk(const KParams<T>& P, WaveWork& w, uint
 }
 // Refill the queue: the next (up to) 64 samples of the cursor, all lanes generating (main.rs:813-820).  False when the
 // global work queue is exhausted and nothing was generated.
-template <typename T, uint32_t QN>
+template <typename T>
 DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32) {
+    const uint32_t QN = P.queue_entries;          // 16, 32 or 64 (wave-uniform: the host gives BVH kernels what LDS the node cache leaves)
     const uint32_t n_px = P.W * P.H;
     bool have = false;
     uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
@@ -1021,16 +1024,17 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
 }
 // Lanes with `dead` set take the next camera path from the wave's queue ("compaction by regeneration").  True for the
 // lanes that got one (ray, rng, new_px, path_s are then the new path's).
-template <typename T, uint32_t QN>
+template <typename T>
 DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32, bool dead,
                         RayT<T>& ray, Rng& rng, uint32_t& new_px, uint32_t& path_s) {
+    const uint32_t QN = P.queue_entries;
     bool got_new = false;
     for (;;) {
         unsigned long long want = __ballot(dead && !got_new);
         if (want == 0) break;
         if (w.q_count == 0) {
             if (w.queue_done) break;
-            if (!refill_queue<T, QN>(P, w, lane, q_real, q_u32)) break;
+            if (!refill_queue(P, w, lane, q_real, q_u32)) break;
         }
         uint32_t n_want = (uint32_t)__popcll(want);
         uint32_t take = n_want < w.q_count ? n_want : w.q_count;
@@ -1200,7 +1204,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_T0();
         // ---- lanes whose path has ended take the next camera path from the wave's queue
         uint32_t new_px = 0;
-        const bool got_new = take_new_paths<T, Shape<FEATS>::QN>(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
+        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
         if (__ballot(alive || got_new) == 0) break;     // queue empty and every path finished
         DIAG_ADD(0);
 
@@ -1394,9 +1398,11 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 phase = PH_OBJ; my_oi = 0; closest = Lim<T>::inf(); any_hit = false;
             }
         }
+        DIAG_ADD(1);
         // ---- lanes whose path has ended take the next camera path from the wave's queue
         uint32_t new_px = 0;
-        const bool got_new = take_new_paths<T, Shape<FEATS>::QN>(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
+        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
+        DIAG_ADD(2);
         // ---- lanes moving on to another pixel hand in their partial sum
         flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
         if (got_new) {
@@ -1410,6 +1416,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 phase = PH_NEW;
             }
         }
+        DIAG_ADD(3);
         // ---- world.hit (main.rs:48), resumable: objects in push order from my_oi up to the next BVH object or the end
         for (uint32_t oi = 0; oi < P.n_objects; oi++) {
             const bool here = phase == PH_OBJ && my_oi == oi;
@@ -1424,7 +1431,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 }
             }
         }
-        DIAG_ADD(1);
+        DIAG_ADD(4);
     }
     // ---- the queue is empty: hand in what is left
     flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
@@ -1444,7 +1451,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
 // ------------------------------------------------------------------ the kernel
 template <typename T, uint32_t FEATS>
 __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER_SIMD) pathtrace_kernel(const KParams<T> P) {
-    // dynamic LDS: [n_cached BVH nodes] [WAVES][regen_bytes(QN)] camera-path queues [WAVES][stack_depth][64] BVH stacks
+    // dynamic LDS: [n_cached BVH nodes] [WAVES][regen_bytes(queue_entries)] camera-path queues [WAVES][stack_depth][64] BVH stacks
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
     const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
@@ -1455,10 +1462,11 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
         for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
         __syncthreads();
     }
-    unsigned char* regen = lds_raw + nodes_bytes + wave_in_block * regen_bytes(S::QN);
+    const uint32_t QN = P.queue_entries;
+    unsigned char* regen = lds_raw + nodes_bytes + wave_in_block * regen_bytes(QN);
     T* q_real = (T*)regen;                                         // [7][QN]: o.x o.y o.z d.x d.y d.z time
-    uint32_t* q_u32 = (uint32_t*)(regen + 7u * S::QN * sizeof(T)); // [6][QN]: rng s0..s3, local pixel, sample
-    uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(S::QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
+    uint32_t* q_u32 = (uint32_t*)(regen + 7u * QN * sizeof(T));    // [6][QN]: rng s0..s3, local pixel, sample
+    uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
     if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack);
     else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack);
 }
@@ -1484,7 +1492,7 @@ static int occupancy_one(size_t shmem) {
     if (Shape<FEATS>::ONE_PER_CU && nb > 1) nb = 1;       // the register budget is set for exactly one such workgroup per CU
     return nb;
 }
-template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; return g; }
+template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN_MIN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; return g; }
 
 // Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
 // Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
