@@ -205,6 +205,10 @@ int rt_last_flush_count(rt_scene*, unsigned long long* out);
 int rt_last_traversal_stats(rt_scene*, unsigned long long out4[4]);
 /* Diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections (zeros in a normal build). */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out6[6]);
+/* Test aid: AABB::hit (src/aabb.rs:19-36) evaluated on the device for n (box, ray, [t_min, t_max]) triples given as host arrays
+ * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
+ * traversal uses for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300).  Non-zero on a HIP error. */
+int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out);
 /* Debug/parity aid: like rt_render but also returns every sample's radiance (W*H*spp*3 doubles). */
 int rt_render_samples(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
                       uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,

@@ -33,7 +33,7 @@ static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_er
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> static void free_device_scene(DeviceScene<T>& d) {
     free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
-    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
+    free_dev(d.bvh); free_dev(d.bvh_soa); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
     d.valid = false;
 }
 
@@ -391,6 +391,14 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DMSphere<T>>(f.mspheres, d.mspheres)) return -1;
     if (upload_vec<DTri<T>>(f.tris, d.tris)) return -1;
     if (upload_vec<DBvhNode<T>>(f.bvh, d.bvh)) return -1;
+    {   // field-wise copy of the nodes (a few KB; only the RT_NODE_SOA measurement build reads it)
+        const size_t n = f.bvh.size();
+        std::vector<T> soa((6 * n + 2 * n) + 8, T(0));                  // u32 a, b, c packed behind the bounds (3n u32 <= 2n reals for f32, 1.5n for f64)
+        for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) { soa[(size_t)k * n + i] = (T)f.bvh[i].mn[k]; soa[(size_t)(3 + k) * n + i] = (T)f.bvh[i].mx[k]; }
+        uint32_t* u = (uint32_t*)(soa.data() + 6 * n);
+        for (size_t i = 0; i < n; i++) { u[i] = f.bvh[i].a; u[n + i] = f.bvh[i].b; u[2 * n + i] = f.bvh[i].c; }
+        if (upload_raw(soa, d.bvh_soa)) return -1;
+    }
     if (upload_vec<DMaterial<T>>(f.materials, d.materials)) return -1;
     if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
     if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
@@ -462,13 +470,15 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
 
 // BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
 // queues and stacks; 0 for the list-scene kernels.
-template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop) {
+template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop, uint32_t stack_depth) {
     if (!g.one_per_cu || f.bvh.empty()) return 0u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     if (lds_total < 65536u) lds_total = 65536u;
-    const size_t fixed = pathtrace_lds_bytes(g, f.bvh_depth, 0u, sizeof(DBvhNode<T>));
+    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, sizeof(DBvhNode<T>));
     if (fixed + sizeof(DBvhNode<T>) > lds_total) return 0u;
-    const size_t room = (lds_total - fixed) / sizeof(DBvhNode<T>);
+    size_t room = (lds_total - fixed) / sizeof(DBvhNode<T>);
+    // RT_NODE_CACHE_MAX (tests, A/B runs): stage at most that many nodes (0 = every node comes from global memory); scheduling only
+    if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
     return (uint32_t)std::min(room, f.bvh.size());
 }
 
@@ -487,10 +497,12 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.objects = (const DObject*)d.objects; P.n_objects = (uint32_t)f.objects.size();
     P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
+    P.bvh_soa = (const T*)d.bvh_soa; P.n_bvh = (uint32_t)f.bvh.size();
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     P.stack_depth = f.bvh_depth;
+    if (const char* v = std::getenv("RT_STACK_DEPTH_MIN")) { const long n = std::strtol(v, nullptr, 10); if (n > (long)P.stack_depth && n <= RT_MAX_BVH_DEPTH) P.stack_depth = (uint32_t)n; }   // A/B runs only
     {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
         const double big = sizeof(T) == 8 ? 1e300 : 1e30;
         bool tame = f.bvh_tame;
@@ -528,12 +540,13 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
 
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     LaunchShape shape = pathtrace_shape(f.feats, P.flags);
-    P.n_cached = cached_nodes<T>(shape, f, prop);
+    P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth);
     // the camera-path queue: the kernel family's minimum, widened (refills at full lane occupancy) while every node still fits
     for (uint32_t q = 64u; q > shape.queue_entries; q >>= 1) {
         LaunchShape wide = shape; wide.queue_entries = q;
-        if (cached_nodes<T>(wide, f, prop) == P.n_cached) { shape = wide; break; }
+        if (cached_nodes<T>(wide, f, prop, P.stack_depth) == P.n_cached) { shape = wide; break; }
     }
+    if (const char* v = std::getenv("RT_QUEUE_ENTRIES")) { const long n = std::strtol(v, nullptr, 10); if (n == 16 || n == 32 || n == 64) shape.queue_entries = (uint32_t)n; }   // A/B runs only
     P.queue_entries = shape.queue_entries;
     size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
@@ -617,8 +630,8 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     const LaunchShape shape = pathtrace_shape(s.flat.feats, eff);
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, cp->device));
     int bpc;
-    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<float>(shape, s.flat, prop), sizeof(DBvhNode<float>)));
-    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<double>(shape, s.flat, prop), sizeof(DBvhNode<double>)));
+    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<float>(shape, s.flat, prop, s.flat.bvh_depth), sizeof(DBvhNode<float>)));
+    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<double>(shape, s.flat, prop, s.flat.bvh_depth), sizeof(DBvhNode<double>)));
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;

@@ -80,6 +80,8 @@ template <typename T> struct KParams {
     const DMSphere<T>* mspheres;
     const DTri<T>* tris;
     const DBvhNode<T>* bvh;
+    const T* bvh_soa; uint32_t n_bvh;      // the same nodes field by field ([6][n_bvh] bounds, then [3][n_bvh] u32 a, b, c): read only by the
+                                           // -DRT_NODE_SOA build, which exists to measure the structure-of-arrays layout
     const DMaterial<T>* materials;
     const DTexture<T>* textures;
     const DMedium<T>* media;

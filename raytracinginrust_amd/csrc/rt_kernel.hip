@@ -391,7 +391,16 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 // CU: the BVH kernels run one workgroup per CU) and a visit there is four ds_read_b128 instead of four global loads.
 template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t node) {
     if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * (uint32_t)sizeof(DBvhNode<T>));
+#ifdef RT_NODE_SOA      // measurement build only: the north_star's field-wise structure-of-arrays node layout
+    DBvhNode<T> nd;
+    const uint32_t n = P.n_bvh;
+    for (uint32_t k = 0; k < 3u; k++) { nd.mn[k] = cl(P.bvh_soa + k * n + node); nd.mx[k] = cl(P.bvh_soa + (3u + k) * n + node); }
+    const uint32_t* u = (const uint32_t*)(P.bvh_soa + 6u * n);
+    nd.a = cl(u + node); nd.b = cl(u + n + node); nd.c = cl(u + 2u * n + node); nd.pad = 0;
+    return nd;
+#else
     return ld_node_at(P.bvh, node);
+#endif
 }
 
 template <typename T, uint32_t FEATS>
@@ -1239,6 +1248,19 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
                     Rec<T> rec;
                     finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
                     DIAG_ADD(3);
+#ifdef RT_REC_LDS       // measurement build only: the north_star's "current hit record staged in LDS" — the record goes
+                        // through the lane's LDS column (here: the wave's BVH-stack area, unused in list scenes) between hit and material
+                    {
+                        T* col = (T*)(stack - (threadIdx.x & 63u)) + (threadIdx.x & 63u);
+                        col[0 * 64] = rec.p.x; col[1 * 64] = rec.p.y; col[2 * 64] = rec.p.z; col[3 * 64] = rec.n.x; col[4 * 64] = rec.n.y; col[5 * 64] = rec.n.z;
+                        col[6 * 64] = rec.t; col[7 * 64] = rec.u; col[8 * 64] = rec.v;
+                        uint32_t* cu = (uint32_t*)(col - (threadIdx.x & 63u) + 9 * 64) + (threadIdx.x & 63u);
+                        cu[0] = rec.front ? 1u : 0u; cu[64] = rec.mat;
+                        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
+                        rec.p = mk<T>(col[0 * 64], col[1 * 64], col[2 * 64]); rec.n = mk<T>(col[3 * 64], col[4 * 64], col[5 * 64]);
+                        rec.t = col[6 * 64]; rec.u = col[7 * 64]; rec.v = col[8 * 64]; rec.front = cu[0] != 0u; rec.mat = cu[64];
+                    }
+#endif
                     shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
                 }
             }
@@ -1551,3 +1573,39 @@ template int pathtrace_blocks_per_cu<float>(uint32_t, uint32_t, size_t);
 #endif
 
 } // namespace rt
+
+#if RT_TU != 1
+// ------------------------------------------------------------------ known-answer access to AABB::hit on the device (tests only)
+namespace rt {
+__global__ void aabb_kat_kernel(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    DBvhNode<double> nd;
+    for (int k = 0; k < 3; k++) { nd.mn[k] = boxes[i * 6 + k]; nd.mx[k] = boxes[i * 6 + 3 + k]; }
+    nd.a = nd.b = nd.c = nd.pad = 0;
+    const V3<double> o = mk<double>(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
+    const V3<double> d = mk<double>(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    const V3<double> inv = mk<double>(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
+    const bool exact = box_inside_exact(nd, o, inv, tlim[i * 2], tlim[i * 2 + 1]);
+    const bool tame_ray = ray_is_tame(o, inv);
+    const bool tame = box_inside_tame(nd, o, inv, tlim[i * 2], tlim[i * 2 + 1]);
+    out[i] = (exact ? 1 : 0) | (tame ? 2 : 0) | (tame_ray ? 4 : 0);
+}
+}
+// out[i]: bit 0 = AABB::hit by the exact form, bit 1 = by the NaN-free form, bit 2 = the ray qualifies for the NaN-free form.
+// boxes: n x (min[3], max[3]); rays: n x (origin[3], direction[3]); tlim: n x (t_min, t_max).  Host pointers.
+extern "C" int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out) {
+    if (n == 0) return 0;
+    double *db = nullptr, *dr = nullptr, *dt = nullptr; int* dout = nullptr;
+    int rc = -1;
+    if (hipMalloc(&db, n * 48ull) == hipSuccess && hipMalloc(&dr, n * 48ull) == hipSuccess && hipMalloc(&dt, n * 16ull) == hipSuccess &&
+        hipMalloc(&dout, n * sizeof(int)) == hipSuccess &&
+        hipMemcpy(db, boxes, n * 48ull, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dr, rays, n * 48ull, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dt, tlim, n * 16ull, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(rt::aabb_kat_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, n, db, dr, dt, dout);
+        if (hipGetLastError() == hipSuccess && hipMemcpy(out, dout, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    (void)hipFree(db); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dout);
+    return rc;
+}
+#endif

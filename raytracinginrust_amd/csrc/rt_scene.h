@@ -40,7 +40,7 @@ struct HostFlat {             // canonical f64 flattening
 template <typename T> struct DeviceScene {   // device copies of HostFlat for one arithmetic type
     bool valid = false;
     void* objects = nullptr; void* ops = nullptr; void* rects = nullptr; void* spheres = nullptr; void* mspheres = nullptr;
-    void* tris = nullptr; void* bvh = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
+    void* tris = nullptr; void* bvh = nullptr; void* bvh_soa = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
     void* lights = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr;
 };
 

@@ -621,3 +621,58 @@ def test_4k_frame_index_ranges(pbe):
     assert max(means) / min(means) < 1.03                  # no aliasing between tile columns and ranks
     small = R.render(b, cam, bg, W // 8, H // 8, 64, depth)
     assert full.mean() / spp == pytest.approx(small.mean() / 64, rel=0.05)
+
+
+@pytest.mark.parametrize("name", ["random", "final", "teapot"])
+def test_lds_node_cache_is_scheduling_only(name, pbe, earth, monkeypatch):
+    """The BVH kernels stage the top levels of the trees in LDS (one workgroup per CU); where a node is fetched from changes no
+    sample.  RT_NODE_CACHE_MAX limits the staged nodes (0 = none, 100 = a partial cache)."""
+    b, cam, bg = build_scene(name, pbe, earth)
+    W, H, spp, depth = 64, 48, 8, 30
+    _, full = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    info = R.last_launch_info(b)
+    assert info["bvh_nodes_in_lds"] > 0 and info["workgroups_per_cu"] == 1 and info["threads"] in (768, 1024)
+    for limit in ("0", "100"):
+        monkeypatch.setenv("RT_NODE_CACHE_MAX", limit)
+        _, part = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+        assert R.last_launch_info(b)["bvh_nodes_in_lds"] == min(int(limit), info["bvh_nodes"])
+        assert np.array_equal(full.view(np.uint64), part.view(np.uint64))
+    monkeypatch.delenv("RT_NODE_CACHE_MAX")
+
+
+def test_aabb_hit_on_the_device_against_the_oracle(pbe, obe):
+    """AABB::hit (src/aabb.rs:19-36) on the device vs the oracle's, on random and on hostile inputs: rays through box corners and
+    along faces, zero direction components (1/d = inf, 0 * inf = NaN which f64::max / min ignore), infinite / NaN origins, inverted
+    boxes.  The traversal's NaN-free form must agree with the reference's form wherever it may be used (tame ray, min <= max)."""
+    import ctypes as C
+    rnd = np.random.default_rng(7)
+    n = 20000
+    lo = rnd.uniform(-10, 10, (n, 3)); ext = rnd.uniform(0, 5, (n, 3))
+    boxes = np.concatenate([lo, lo + ext], axis=1)
+    o = rnd.uniform(-20, 20, (n, 3)); d = rnd.normal(size=(n, 3))
+    tl = np.stack([np.full(n, 1e-5), rnd.choice([np.inf, 5.0, 50.0], n)], axis=1)
+    special = [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-320, 1e300, -1e300, 1e308]
+    for i in range(0, n, 4):                 # every 4th case gets hostile components
+        k = rnd.integers(0, 3)
+        which = rnd.integers(0, 6)
+        if which == 0: d[i, k] = rnd.choice([0.0, -0.0])
+        elif which == 1: o[i, k] = boxes[i, k]; d[i, (k + 1) % 3] = 0.0          # origin on the min face, axis-parallel: 0 * inf
+        elif which == 2: o[i, k] = rnd.choice(special)
+        elif which == 3: d[i, k] = rnd.choice(special)
+        elif which == 4: boxes[i, k], boxes[i, 3 + k] = boxes[i, 3 + k], boxes[i, k] - 1.0   # inverted box
+        else: o[i] = boxes[i, :3]; d[i] = boxes[i, 3:] - boxes[i, :3]             # through two corners
+    rays = np.concatenate([o, d], axis=1)
+    out = np.zeros(n, dtype=np.int32)
+    lib = pbe.lib
+    lib.rt_debug_aabb_hit.restype = C.c_int
+    lib.rt_debug_aabb_hit.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    boxes, rays, tl = (np.ascontiguousarray(x, dtype=np.float64) for x in (boxes, rays, tl))
+    assert lib.rt_debug_aabb_hit(n, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, out.ctypes.data) == 0
+    from oracle import orc
+    d3 = lambda v: orc._d(*v)
+    ref = np.array([obe.lib.orc_aabb_hit(d3(boxes[i, :3]), d3(boxes[i, 3:]), d3(rays[i, :3]), d3(rays[i, 3:]), tl[i, 0], tl[i, 1]) for i in range(n)])
+    assert np.array_equal(out & 1, ref), f"{int(((out & 1) != ref).sum())} of {n} box tests differ from the oracle"
+    box_tame = (boxes[:, :3] <= boxes[:, 3:]).all(axis=1) & np.isfinite(boxes).all(axis=1)
+    use = ((out & 4) != 0) & box_tame
+    assert use.sum() > n // 2 and (~use).sum() > 100
+    assert np.array_equal((out[use] >> 1) & 1, ref[use]), "the NaN-free form disagrees where it would be used"

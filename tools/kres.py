@@ -7,7 +7,7 @@ ap.add_argument("--flags", default="")
 a = ap.parse_args()
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracinginrust_amd", "csrc")
 extra = a.flags.split()
-if a.tu == "1": extra = ["-O2", "-mllvm", "-enable-misched=0"] + extra
+if a.tu == "1": extra = ["-mllvm", "-enable-misched=0"] + extra
 obj = a.keep or f"/tmp/kres_{os.getpid()}.o"
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wno-unused-function", "--offload-arch=gfx950",
        f"-DRT_TU={a.tu}", "-I" + csrc, "-c", a.src if os.path.isabs(a.src) else os.path.join(csrc, a.src), "-o", obj, "-Rpass-analysis=kernel-resource-usage"] + extra
