@@ -55,6 +55,12 @@
 #ifndef RT_WAVES_PBR
 #define RT_WAVES_PBR 3
 #endif
+// Per-pixel partial sums of the BVH kernels in the lane's LDS column instead of six VGPRs: *measured* (round 2, A/B in one process)
+// slower — random spheres -3.5 %, final scene -2 %, teapot room -6 % (the 24 KB per CU come out of the node cache, and the kernels
+// spill about as much either way) — so registers it is; the option stays for the measurement.
+#ifndef RT_ACC_LDS
+#define RT_ACC_LDS 0
+#endif
 #ifndef RT_WW_NUM
 #define RT_WW_NUM 3u
 #define RT_WW_DEN 8u
@@ -881,6 +887,11 @@ template <typename T> DEV V3<T> brdf_pdf_generate(const DPbr<T>& m, const Onb<T>
     return onb_local(uvw, reflect_(r_in, wh));
 }
 
+// A lane's partial sum of one pixel: three f64.  In registers for the list-scene kernels; the BVH kernels keep it in the lane's LDS
+// column instead (touched once per finished path, it would otherwise sit in — or be spilled from — six VGPRs through every traversal).
+struct AccReg { double v[3]; DEV double get(int k) const { return v[k]; } DEV void set(int k, double x) { v[k] = x; } };
+struct AccLds { double* col; DEV double get(int k) const { return col[k * 64]; } DEV void set(int k, double x) { col[k * 64] = x; } };
+
 // ------------------------------------------------------------------ launch geometry per kernel family
 // List scenes: 256-thread workgroups, several per CU.  BVH scenes: ONE workgroup per CU holding every wave the register budget
 // allows (4 per SIMD = 1024 threads; 3 = 768 for the persistent-traversal and the principled-material kernels), so that the CU's
@@ -891,6 +902,11 @@ template <uint32_t FEATS> struct Shape {
     static constexpr uint32_t WAVES = ONE_PER_CU ? 4u * WAVES_PER_SIMD : 4u;
     static constexpr uint32_t THREADS = 64u * WAVES;
     static constexpr uint32_t QN_MIN = ONE_PER_CU ? 16u : 64u;    // camera-path queue entries per wave: at least this, up to 64 (KParams::queue_entries)
+    static constexpr bool ACC_IN_LDS = RT_ACC_LDS && ONE_PER_CU;  // per-pixel partial sums in the lane's LDS column (1.5 KB per wave)
+    typedef typename std::conditional<ACC_IN_LDS, AccLds, AccReg>::type Acc;
+    static DEV Acc make_acc(double* col) { Acc a; assign_acc(a, col); return a; }
+    static DEV void assign_acc(AccLds& a, double* col) { a.col = col; }
+    static DEV void assign_acc(AccReg&, double*) {}
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -906,15 +922,16 @@ DEV double wave_sum(double x) {                      // fixed butterfly: determi
 // Lanes with `need` set hold a partial per-pixel sum (acc) for local pixel acc_px.  All partials of one pixel are
 // combined by a masked butterfly and added to out[] by one lane with one f64 atomic per channel (a handful per pixel
 // per frame: this is the kernel's only global write traffic).
-DEV void flush_acc(bool need, uint32_t acc_px, const double acc[3], double* out, uint32_t lane, uint32_t& n_flush) {
+template <typename A>
+DEV void flush_acc(bool need, uint32_t acc_px, const A& acc, double* out, uint32_t lane, uint32_t& n_flush) {
     unsigned long long m = __ballot(need);
     while (m) {
         uint32_t leader = (uint32_t)__builtin_ctzll(m);
         uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)acc_px, (int)leader);
         bool mine = need && acc_px == px;
-        double s0 = wave_sum(mine ? acc[0] : 0.0);
-        double s1 = wave_sum(mine ? acc[1] : 0.0);
-        double s2 = wave_sum(mine ? acc[2] : 0.0);
+        double s0 = wave_sum(mine ? acc.get(0) : 0.0);
+        double s1 = wave_sum(mine ? acc.get(1) : 0.0);
+        double s2 = wave_sum(mine ? acc.get(2) : 0.0);
         if (lane == leader) {
             double* o = out + (size_t)px * 3u;        // hardware f64 atomics: a pixel's samples may be split over several waves
             unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2);
@@ -1163,10 +1180,10 @@ DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& 
 
 // A finished path hands in beta * e (kept even when e = 0, so that inf * 0 = NaN poisons a sample exactly when the
 // reference's arithmetic does).
-template <typename T>
-DEV void add_radiance(const KParams<T>& P, V3<T> L, double acc[3], uint32_t& n_nonfinite, uint32_t path_px, uint32_t path_s) {
+template <typename T, typename A>
+DEV void add_radiance(const KParams<T>& P, V3<T> L, A& acc, uint32_t& n_nonfinite, uint32_t path_px, uint32_t path_s) {
     double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
-    acc[0] += l0; acc[1] += l1; acc[2] += l2;
+    acc.set(0, acc.get(0) + l0); acc.set(1, acc.get(1) + l1); acc.set(2, acc.get(2) + l2);
     if (!(l0 - l0 == 0.0 && l1 - l1 == 0.0 && l2 - l2 == 0.0)) n_nonfinite++;
     if (P.samples_out) {
         double* so = P.samples_out + ((size_t)path_px * P.spp + path_s) * 3u;
@@ -1194,7 +1211,7 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
 // wave-uniform object list, hit record, material).  Used when the scene has no BVH: every lane's closest-hit search costs
 // the same, so lock-step wastes nothing.
 template <typename T, uint32_t FEATS>
-DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack) {
+DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack, double* acc_col) {
     WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
     // per-lane path state
     bool alive = false;
@@ -1204,7 +1221,8 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
-    double acc[3] = {0.0, 0.0, 0.0};
+    typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
+    acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0;
     DIAG_DECL
@@ -1221,7 +1239,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
 
         if (got_new) {
-            if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
+            if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
             path_px = new_px;
             beta = mk<T>(T(1.0), T(1.0), T(1.0));
             depth_left = P.max_depth;
@@ -1298,7 +1316,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 enum : uint32_t { PH_NEW = 0u, PH_OBJ = 1u, PH_BVH = 2u, PH_SHADE = 3u };
 
 template <typename T, uint32_t FEATS>
-DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack) {
+DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack, double* acc_col) {
     WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
     const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;
     // per-lane path state
@@ -1319,7 +1337,8 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
     bool tv_any = false, tv_have_leaf = false;
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
-    double acc[3] = {0.0, 0.0, 0.0};
+    typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
+    acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0;
     DIAG_DECL
@@ -1428,7 +1447,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         // ---- lanes moving on to another pixel hand in their partial sum
         flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
         if (got_new) {
-            if (acc_px != new_px) { acc_px = new_px; acc[0] = acc[1] = acc[2] = 0.0; }
+            if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
             path_px = new_px;
             beta = mk<T>(T(1.0), T(1.0), T(1.0));
             depth_left = P.max_depth;
@@ -1474,6 +1493,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
 template <typename T, uint32_t FEATS>
 __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER_SIMD) pathtrace_kernel(const KParams<T> P) {
     // dynamic LDS: [n_cached BVH nodes] [WAVES][regen_bytes(queue_entries)] camera-path queues [WAVES][stack_depth][64] BVH stacks
+    //              [WAVES][3][64] f64 per-pixel partial sums (BVH kernels)
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
     const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
@@ -1489,8 +1509,9 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     T* q_real = (T*)regen;                                         // [7][QN]: o.x o.y o.z d.x d.y d.z time
     uint32_t* q_u32 = (uint32_t*)(regen + 7u * QN * sizeof(T));    // [6][QN]: rng s0..s3, local pixel, sample
     uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
-    if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack);
-    else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack);
+    double* acc_col = (double*)(lds_raw + nodes_bytes + S::WAVES * (regen_bytes(QN) + P.stack_depth * 256u)) + wave_in_block * (3u * 64u) + lane;   // (ACC_IN_LDS kernels)
+    if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col);
+    else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col);
 }
 
 // ------------------------------------------------------------------ launch
@@ -1514,7 +1535,7 @@ static int occupancy_one(size_t shmem) {
     if (Shape<FEATS>::ONE_PER_CU && nb > 1) nb = 1;       // the register budget is set for exactly one such workgroup per CU
     return nb;
 }
-template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN_MIN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; return g; }
+template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN_MIN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; g.acc_in_lds = Shape<FEATS>::ACC_IN_LDS; return g; }
 
 // Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
 // Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),

@@ -6,12 +6,12 @@
 namespace rt {
 // Shape of the instantiation that serves a scene: workgroup size, entries of each wave's camera-path queue (80 B each), and whether
 // it runs as ONE workgroup per CU (BVH kernels: the CU's LDS then holds one copy of the top of the BVH, KParams::n_cached nodes).
-struct LaunchShape { uint32_t threads, queue_entries; bool one_per_cu; };
+struct LaunchShape { uint32_t threads, queue_entries; bool one_per_cu, acc_in_lds; };
 LaunchShape pathtrace_shape(uint32_t scene_feats, uint32_t flags);
-// Dynamic LDS of one workgroup: [n_cached nodes][waves x queue][waves x stack_depth x 64 dwords]
+// Dynamic LDS of one workgroup: [n_cached nodes][waves x queue][waves x stack_depth x 64 dwords][waves x 3 x 64 f64 partial sums]
 inline size_t pathtrace_lds_bytes(const LaunchShape& g, uint32_t stack_depth, uint32_t n_cached, size_t node_bytes) {
     const size_t waves = g.threads / 64u;
-    return (size_t)n_cached * node_bytes + waves * ((size_t)g.queue_entries * 80u + (size_t)stack_depth * 64u * sizeof(uint32_t));
+    return (size_t)n_cached * node_bytes + waves * ((size_t)g.queue_entries * 80u + (size_t)stack_depth * 64u * sizeof(uint32_t) + (g.acc_in_lds ? 3u * 64u * 8u : 0u));
 }
 // Counter block the kernel reports into: RT_STATS_ROWS copies (row = block index mod rows) of RT_STATS_SLOTS 64-bit counters
 static const uint32_t RT_STATS_SLOTS = 16u, RT_STATS_ROWS = 32u;
