@@ -41,19 +41,25 @@ def assemble(gathered: torch.Tensor, W: int, H: int, tile_px: int) -> torch.Tens
     return frame[: W * H].reshape(H, W, 3)
 
 
-def gather_frame(local: torch.Tensor, W: int, H: int, tile_px: int, dst: int = 0):
-    """`local`: this rank's [n_local, tile_px, 3] buffer.  Returns the (H, W, 3) frame on `dst`, None elsewhere."""
+def gather_frame(local: torch.Tensor, W: int, H: int, tile_px: int, dst: int = 0, gathered: torch.Tensor | None = None):
+    """`local`: this rank's [n_local, tile_px, 3] buffer.  Returns the (H, W, 3) frame on `dst`, None elsewhere.  The one collective
+    writes straight into the rows of `gathered` ([world, n_local, tile_px, 3], reusable; allocated here if not given), and the frame
+    is ONE strided copy out of it (the un-permute): no intermediate stack of the per-rank buffers."""
     world, rank = dist.get_world_size(), dist.get_rank()
     if world == 1:
         return assemble(local.unsqueeze(0), W, H, tile_px)
     staged = local
     if local.is_cuda and dist.get_backend() == "gloo":      # gloo (CPU tests / single-GPU development) gathers host tensors
         staged = local.cpu()
-    bufs = [torch.empty_like(staged) for _ in range(world)] if rank == dst else None
+    bufs = None
+    if rank == dst:
+        if gathered is None or gathered.device != staged.device or tuple(gathered.shape) != (world,) + tuple(staged.shape):
+            gathered = torch.empty((world,) + tuple(staged.shape), dtype=staged.dtype, device=staged.device)
+        bufs = list(gathered.unbind(0))                      # views: the gather's receive buffers ARE the rows
     dist.gather(staged, bufs, dst=dst)
     if rank != dst:
         return None
-    return assemble(torch.stack(bufs, 0).to(local.device), W, H, tile_px)
+    return assemble(gathered, W, H, tile_px).to(local.device)
 
 
 class TileRenderer:
@@ -83,6 +89,7 @@ class TileRenderer:
         # queue and the launches did not overlap at all (measured)
         self.streams = [torch.cuda.Stream(self.device, priority=-(k % 2)) for k in range(pipeline)] if pipeline > 1 else []
         self.frames = 0
+        self._gathered = []            # rank `dst` only: receive buffers of the gather, one per frame in flight
 
     def render_local(self, buf=None) -> torch.Tensor:
         """Launch the path-tracing kernel for this rank's tiles on torch's current stream (asynchronous)."""
@@ -96,6 +103,13 @@ class TileRenderer:
         local = self.render_local(buf)
         if self.world == 1:
             return assemble(local.unsqueeze(0), self.W, self.H, self.tile_px)
+        if self.rank == dst and not (local.is_cuda and dist.get_backend() == "gloo"):
+            k = self.frames % self.pipeline if self.pipeline > 1 else 0      # one receive buffer per frame in flight
+            if len(self._gathered) <= k:
+                self._gathered.extend([None] * (k + 1 - len(self._gathered)))
+            if self._gathered[k] is None:
+                self._gathered[k] = torch.empty((self.world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+            return gather_frame(local, self.W, self.H, self.tile_px, dst, self._gathered[k])
         return gather_frame(local, self.W, self.H, self.tile_px, dst)
 
     def render_frame(self, dst: int = 0):
