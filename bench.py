@@ -16,8 +16,8 @@ this is a model figure, not HBM utilisation: physical traffic (`traffic`) and wh
 `valu_roofline` — come from the committed rocprofv3 --pmc passes of this same command and are used only when that profile was
 taken on THIS build of the kernels (matching `kernel_source_id`); otherwise they are null.
 
-`workloads`: the other BASELINE configs (C1, C3, C4, C5) timed the same way, one reduced-spp warm-up frame + one full frame each,
-so that every config's Msamples/s and roofline fraction is on the driver's clock.
+`workloads`: the other BASELINE configs (C1, C3, C4, C5) timed the same way, one reduced-spp warm-up frame + one full frame each
+(twenty for C1, whose frame is a few milliseconds), so that every config's Msamples/s and roofline fraction is on the driver's clock.
 
 `cpu_baseline` (N = 1 only): the CPU oracle — a restatement of the reference, not the Rust binary, which cannot be built here —
 on a bounded sample of the same workload, in both threading shapes BASELINE.md names, counters compiled out.
@@ -251,7 +251,7 @@ def main():
         # HIP events around every kernel on its own launch stream, summed by the library (no host stop after each frame)
         k_total_ms, k_launches = R.kernel_time_total(b)
         assert k_launches == steps
-        res = {"w": w, "elapsed": elapsed, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
+        res = {"w": w, "elapsed": elapsed, "steps": steps, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
                "pipeline": tr.pipeline}
         if rank == 0:
             assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
@@ -271,7 +271,8 @@ def main():
         for key in args.also.split(","):
             if key and key != w.key:
                 we = workloads.WORKLOADS[key]
-                extra.append(run(we, 1, 1, warm_spp=max(1, we.spp // 32)))
+                # one full frame each; a frame of a few milliseconds (C1) is timed over 20 so that the figure is not launch jitter
+                extra.append(run(we, 20 if we.samples < 50_000_000 else 1, 1, warm_spp=max(1, we.spp // 32)))
 
     if rank == 0:
         with_pmc = world == 1 and not args.f32 and not args.near_first and not args.sah
@@ -285,8 +286,8 @@ def main():
         for r in extra:
             we = r["w"]
             ro, va = roofline_of(we, workloads.BYTES_PER_SAMPLE[we.key], r["local_samples"], r["k_ms"], r["n_flush"], kernel_name_of(we, args.f32), with_pmc)
-            others[we.key] = {"workload": we.describe(), "value": we.samples / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": 1,
-                              "warmup": f"1 frame at {max(1, we.spp // 32)} spp (same kernel and scene)", "ms_per_step": r["elapsed"] * 1e3,
+            others[we.key] = {"workload": we.describe(), "value": we.samples * r["steps"] / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": r["steps"],
+                              "warmup": f"1 frame at {max(1, we.spp // 32)} spp (same kernel and scene)", "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
                               "kernel_ms": r["k_ms"], "frac": ro["frac"], "bytes_per_sample": ro["bytes_per_sample"],
                               "achieved_GBps": ro["achieved"], "traffic": ro["traffic"], "traffic_source": ro["traffic_source"],
                               "valu_roofline": va, "kernel": ro["kernel"],

@@ -527,12 +527,6 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     uint64_t n_local_px = (uint64_t)P.n_local_tiles * tile_px;
     if (n_local_px >= 0xFFFFFFFFull) return set_err("too many local pixels");
     if ((size_t)n_local_px * 3 * sizeof(double) > d_out_bytes) return set_err("output buffer too small for n_local_tiles * tile_px * 3 doubles");
-    // work chunks of about 256 samples: several pixels per chunk at low spp, several chunks per pixel at high spp
-    // (a fine grain keeps the end-of-frame tail short when the frame is split over many GPUs)
-    const uint32_t CH = 256u;
-    if (spp >= 2u * CH) { P.chunk_px = 1u; P.chunks_per_px = (spp + CH - 1) / CH; P.chunk_spp = (spp + P.chunks_per_px - 1) / P.chunks_per_px; }
-    else { P.chunk_px = (CH + spp - 1) / spp; P.chunks_per_px = 1u; P.chunk_spp = spp; }
-    P.n_coarse_px = 0;
     Scene::LaunchSlot* slot = nullptr;
     if (acquire_slot(s, c, stream, &slot)) return -1;
     P.queue = (uint32_t*)slot->d_queue; P.stats = (unsigned long long*)slot->d_stats;
@@ -557,6 +551,17 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     uint64_t n_blocks = (uint64_t)prop.multiProcessorCount * (uint64_t)bpc;
     if (n_blocks > blocks_needed) n_blocks = blocks_needed;
     if (n_blocks == 0) n_blocks = 1;
+    {   // Work chunks of at most 256 samples: several pixels per chunk at low spp, several chunks per pixel at high spp.  A small frame
+        // (BASELINE config 1: 1400 samples per resident wave) gets smaller ones, down to 64 samples, so that every wave still sees about
+        // 32 of them and the frame does not end with a few waves finishing a last big chunk alone: *measured* on C1, 64-sample chunks
+        // 4.54 ms, 128 4.88 ms, 256 5.46 ms per frame.
+        uint64_t per_wave = (n_local_px * spp) / (n_blocks * waves_per_block * 32ull);
+        uint32_t CH = (uint32_t)std::min<uint64_t>(256u, std::max<uint64_t>(64u, per_wave));
+        if (const char* v = std::getenv("RT_CHUNK_SAMPLES")) { const long n = std::strtol(v, nullptr, 10); if (n >= 16 && n <= 4096) CH = (uint32_t)n; }   // A/B runs only
+        if (spp >= 2u * CH) { P.chunk_px = 1u; P.chunks_per_px = (spp + CH - 1) / CH; P.chunk_spp = (spp + P.chunks_per_px - 1) / P.chunks_per_px; }
+        else { P.chunk_px = (CH + spp - 1) / spp; P.chunks_per_px = 1u; P.chunk_spp = spp; }
+        P.n_coarse_px = 0;
+    }
     {   // split only the last ~1.5 pixels per resident wave into fine chunks
         uint64_t fine_px = n_blocks * waves_per_block * 3ull / 2ull;
         if (P.chunks_per_px > 1 && n_local_px > fine_px) P.n_coarse_px = (uint32_t)(n_local_px - fine_px);
