@@ -8,7 +8,9 @@ from conftest import ROOT
 
 
 def _latest():
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_C2.json")))
+    """The newest committed DEFAULT line (`python bench.py`: C2 headline + CPU baseline + the other configs); round 1 committed
+    only per-workload lines."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_default.json"))) or sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_C2.json")))
     assert files, "no committed bench line"
     return json.loads(open(files[-1]).read().strip().splitlines()[-1])
 
