@@ -135,11 +135,12 @@ def roofline_of(w, bps, local_samples, k_ms, n_flush, kernel_name, with_pmc):
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                 roof["traffic"] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
                 roof["traffic_source"] = f"profiles/{src}: committed rocprofv3 --pmc passes of this command on this build (not measured in this run)"
-            need = ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES", "SQ_THREAD_CYCLES_VALU")
-            if all(k in vals for k in need) and vals["SQ_WAVE_CYCLES"] > 0 and vals["SQ_ACTIVE_INST_VALU"] > 0:
+            need = ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_THREAD_CYCLES_VALU")
+            waves = vals.get("LAUNCH_WAVES", vals.get("SQ_WAVES"))      # grid size / 64 (SQ_WAVES reports double on some dispatches)
+            if waves and all(k in vals for k in need) and vals["SQ_WAVE_CYCLES"] > 0 and vals["SQ_ACTIVE_INST_VALU"] > 0:
                 # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over waves; the grid is persistent, so
-                # SQ_WAVE_CYCLES / SQ_WAVES is the launch's length in quad-cycles and SQ_WAVES / 1024 the waves per SIMD.
-                busy = vals["SQ_ACTIVE_INST_VALU"] * (vals["SQ_WAVES"] / N_SIMD) / vals["SQ_WAVE_CYCLES"]
+                # SQ_WAVE_CYCLES / waves is the launch's length in quad-cycles and waves / 1024 the waves per SIMD.
+                busy = vals["SQ_ACTIVE_INST_VALU"] * (waves / N_SIMD) / vals["SQ_WAVE_CYCLES"]
                 lanes = vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"])
                 valu = {"bound": "f64 VALU issue", "valu_busy_frac": busy, "valu_lane_utilisation": lanes, "frac": busy * lanes,
                         "frac_meaning": "useful VALU lane-slots / VALU lane-slots the SIMDs could have issued over the launch",
