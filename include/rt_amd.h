@@ -51,6 +51,10 @@ enum {
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
+    RT_WAVEFRONT = 128,    /* scheduling only, same samples, BVH scenes only (ignored for list scenes): the frame's paths go through a
+                              pool in HBM in rounds of three kernels — new camera paths / world.hit with lanes that fetch the next
+                              path as soon as their search ends / hit record + material — instead of one persistent kernel.
+                              rt_render_device is synchronous with it.                                                        */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
                               old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };

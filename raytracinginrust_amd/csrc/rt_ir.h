@@ -116,4 +116,23 @@ template <typename T> struct KParams {
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
 };
 
+// Wavefront backend (RT_WAVEFRONT): the paths in flight live in two pools of `P` records in HBM, used in turn: a round reads the live
+// paths at positions [0, n_alive) of one pool and packs the survivors into the other.  One path = ONE aligned record (128 B in f64:
+// a single cache line; 64 B in f32), so that a lane that picks up or hands back a path touches one line, not one line per field.
+template <typename T> struct alignas(16 * sizeof(T)) WfPath {
+    T o[3], d[3], tm;               // the ray (world space) and its time
+    T beta[3];                      // throughput
+    T hit_t; uint32_t hit_obj, hit_prim;     // world.hit's result (hit_obj = 0xFFFFFFFF: no hit): one 16-byte piece in f64
+    uint32_t rng[4];                // xoshiro state
+    uint32_t px, smp, depth;        // local pixel, sample index, bounces left
+};
+template <typename T> struct WfParams {
+    WfPath<T>* in;                  // this round's pool: live paths at [0, n_alive); gen appends n_new behind them
+    WfPath<T>* out;                 // the other pool: shade packs the survivors into it
+    uint32_t P;
+    uint32_t n_alive;
+    uint32_t* counters;             // [1] survivors of the round
+    unsigned long long first_sample; uint32_t n_new;       // gen: sample index (local pixel * spp + sample) of the first new path
+};
+
 } // namespace rt

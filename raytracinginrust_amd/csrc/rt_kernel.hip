@@ -1593,6 +1593,358 @@ template int pathtrace_blocks_per_cu<double>(uint32_t, uint32_t, size_t);
 template int pathtrace_blocks_per_cu<float>(uint32_t, uint32_t, size_t);
 #endif
 
+#if RT_TU != 1
+// ================================================================== wavefront backend for BVH scenes (RT_WAVEFRONT, opt-in)
+// The same per-path arithmetic in the same order, scheduled differently: the paths of a frame live in a pool in HBM (structure of
+// arrays, one slot per path in flight) and every bounce is three launches —
+//   wf_gen    fills free slots with new camera paths (main.rs:813-820)
+//   wf_trace  world.hit for every live path: persistent waves whose lanes FETCH THE NEXT PATH the moment their own search ends, so
+//             a wave's occupancy does not decay to its slowest ray; no material code, no path state besides the ray and its RNG in
+//             registers
+//   wf_shade  hit record + material for every live path, one thread each; finished paths add their radiance to the frame
+//             (partial sums of a wave's lanes that share a pixel are combined first), survivors and freed slots are listed for the
+//             next round.
+// What the megakernel cannot do for BVH scenes — keep traversal lanes busy while neighbours of the same wave finish early, without
+// holding the material code's registers — is the point; the price is ~0.5 KB of HBM traffic per bounce for the path state.
+template <typename T> DEV void wf_camera_path(const KParams<T>& P, uint32_t gp, uint32_t gi, uint32_t gj, uint32_t s, RayT<T>& ray, Rng& g) {
+    g = rng_for_path(P.seed, gp, s);
+    T random_u = rng_u01(g, T(0));
+    T random_v = rng_u01(g, T(0));
+    T u = (T(gi) + random_u) / T(P.W - 1u);
+    T v = (T(gj) + random_v) / T(P.H - 1u);
+    T da, db;                                                   // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
+    for (;;) {
+        da = rng_range(g, T(-1.0), T(1.0));
+        db = rng_range(g, T(-1.0), T(1.0));
+        V3<T> pd = mk<T>(da, db, T(0));
+        if (dot(pd, pd) < T(1.0)) break;
+    }
+    V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
+    V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
+    ray.tm = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
+    ray.o = ld3(P.cam.origin) + offset;
+    ray.d = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
+}
+
+static const uint32_t WF_NO_HIT = 0xFFFFFFFFu;
+// whole-record transfers of a path (one aligned record = one or two cache lines): 16-byte pieces
+template <typename T> DEV void wf_store(WfPath<T>* dst, const WfPath<T>& r) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    const u4* s = (const u4*)&r; u4* d = (u4*)dst;
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(WfPath<T>) / 16u; k++) d[k] = s[k];
+}
+template <typename T> DEV WfPath<T> wf_load(const WfPath<T>* src) {
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    WfPath<T> r; u4* d = (u4*)&r; const u4* s = (const u4*)src;
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(WfPath<T>) / 16u; k++) d[k] = s[k];
+    return r;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) wf_gen_kernel(const KParams<T> P, const WfParams<T> W) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= W.n_new) return;
+    const uint32_t slot = W.n_alive + i;                                   // new paths join the pool behind the survivors
+    const unsigned long long g = W.first_sample + i;
+    const uint32_t lp = (uint32_t)(g / P.spp), smp = (uint32_t)(g - (unsigned long long)lp * P.spp);
+    const uint32_t q = lp / P.tile_px, kk = lp - q * P.tile_px;
+    const uint32_t gp = (P.rank + q * P.world) * P.tile_px + kk;           // local pixel -> output-order pixel (tile t = rank + q * world)
+    const uint32_t row = gp / P.W, gi = gp - row * P.W, gj = P.H - 1u - row;
+    RayT<T> ray; Rng rng;
+    wf_camera_path(P, gp, gi, gj, smp, ray, rng);
+    WfPath<T> rec;
+    rec.o[0] = ray.o.x; rec.o[1] = ray.o.y; rec.o[2] = ray.o.z; rec.d[0] = ray.d.x; rec.d[1] = ray.d.y; rec.d[2] = ray.d.z; rec.tm = ray.tm;
+    rec.beta[0] = rec.beta[1] = rec.beta[2] = T(1.0); rec.hit_t = T(0);
+    rec.rng[0] = rng.s0; rec.rng[1] = rng.s1; rec.rng[2] = rng.s2; rec.rng[3] = rng.s3;
+    rec.hit_obj = WF_NO_HIT; rec.hit_prim = 0; rec.px = lp; rec.smp = smp; rec.depth = P.max_depth;
+    wf_store(W.in + slot, rec);
+}
+
+// world.hit for every live path.  A lane's search is the state machine of trace_resumable (objects in push order; a BVH object is
+// walked node by node with the stack in the lane's LDS column; box and leaf steps chosen by vote), and what replaces the advance
+// pass is small: store a finished search's (t, object, primitive, RNG) and load the next path of the wave's prefetched batch.
+template <typename T, uint32_t FEATS>
+__global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER_SIMD) wf_trace_kernel(const KParams<T> P, const WfParams<T> W) {
+    typedef Shape<FEATS> S;
+    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
+    if (P.n_cached != 0u) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4* src = (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
+        for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
+        __syncthreads();
+    }
+    uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes) + wave_in_block * (P.stack_depth * 64u) + lane;
+    const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;
+    const uint32_t NONE = 0xFFFFFFFFu, BVH_DONE = 0xFFFFFFFFu;
+    // the wave's current batch of pool positions: one per lane, handed out front to back.  Batches of 64 consecutive positions are
+    // dealt round-robin over the grid's waves (no shared cursor: one address takes only ~88 atomics per microsecond and a round
+    // has 65 k batches); the lanes inside a wave are what balances the load.
+    uint32_t batch_slot = NONE, q_head = 0, q_count = 0;
+    bool list_done = false;
+    const uint32_t n_waves_grid = gridDim.x * S::WAVES;
+    uint32_t next_batch = blockIdx.x * S::WAVES + wave_in_block;
+    // per-lane search state
+    uint32_t slot = NONE, phase = PH_NEW, my_oi = 0;
+    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
+    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    T closest = Lim<T>::inf();
+    HitId id; id.obj = 0; id.prim = 0;
+    bool any_hit = false;
+    uint32_t tv_node = 0, tv_sp = 0, tv_prim = 0, tv_best = 0, tv_leaf_a = 0, tv_leaf_b = 0, tv_leaf_node = 0;
+    T tv_closest = T(0);
+    bool tv_any = false, tv_have_leaf = false;
+    // ONE ray per lane: the world-space ray while the lane walks the object list; on entering a BVH object it is replaced by the
+    // object-space ray (the wrapper chain applied) and, when that BVH is done, read back from the pool — the traversal loop then
+    // carries 14 registers less, which is what keeps 1/d (`inv`) out of scratch there.
+    V3<T> inv = ray.o;                           // 1/d of the object-space ray (aabb.rs:21), same value at every node
+    unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0;      // rt_last_traversal_stats
+    DIAG_DECL
+    DIAG_T0();
+
+    for (;;) {
+        const uint32_t n_bvh = (uint32_t)__popcll(__ballot(phase == PH_BVH));
+        const bool work_left = !(list_done && q_count == 0u);
+        const uint32_t n_adv = (uint32_t)__popcll(__ballot(phase == PH_OBJ || (phase == PH_NEW && work_left)));
+        if (n_bvh == 0u && n_adv == 0u) break;
+
+        if (n_bvh >= P.trav_hi || n_adv == 0u) {
+            // ================= traversal pass: until trav_lo lanes are left walking (the others wait for the next hand-over)
+            const T t_min = TMin<T>::v();
+            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !ray_is_tame(ray.o, inv)) == 0ull;
+            uint32_t stop_below = P.trav_lo < n_bvh ? P.trav_lo : n_bvh;
+            if (!work_left && n_adv == 0u) stop_below = 1u;         // nothing to hand over any more: run the stragglers out
+            if (stop_below < 1u) stop_below = 1u;
+            for (;;) {
+                const bool act = phase == PH_BVH;
+                const uint32_t n = (uint32_t)__popcll(__ballot(act));
+                if (n < stop_below) break;
+                const bool want_leaf = act && tv_have_leaf;
+                const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
+                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
+                const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box));
+                n_steps++;
+                if (want_box || want_leaf) n_step_lanes++;
+                if (n_box != 0u && n_leaf * 64u < P.trav_leaf * n) {
+                    if (want_box) {
+                        const DBvhNode<T> nd = fetch_node(P, tv_node);
+                        const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, tv_closest) : box_inside_exact(nd, ray.o, inv, t_min, tv_closest);
+                        if (inside && !(nd.a & BVH_LEAF)) {
+                            const bool right_first = near_first && get(ray.d, nd.a) < T(0);
+                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;
+                            tv_sp++;
+                            tv_node = right_first ? nd.b : nd.c;
+                        } else {
+                            if (inside) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = nd.c; }
+                            if (tv_sp == 0u) tv_node = BVH_DONE;
+                            else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
+                        }
+                    }
+                } else if (n_leaf != 0u) {
+                    if (want_leaf) {
+                        T t; uint32_t prim;
+                        if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, ray, t_min, tv_closest, t, prim) &&
+                            bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
+                        tv_have_leaf = false;
+                    }
+                }
+                if (act && !tv_have_leaf && tv_node == BVH_DONE) {
+                    if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
+                    my_oi++;
+                    phase = PH_OBJ;
+                    if (my_oi < P.n_objects) {             // more objects follow: the world-space ray again (the time never changed)
+                        const WfPath<T>* src = W.in + slot;
+                        ray.o = mk<T>(src->o[0], src->o[1], src->o[2]);
+                        ray.d = mk<T>(src->d[0], src->d[1], src->d[2]);
+                    }
+                }
+            }
+            DIAG_ADD(0);
+            continue;
+        }
+
+        // ================= hand-over pass
+        n_iters++;
+        if (phase == PH_OBJ || phase == PH_NEW) n_active++;
+        // ---- finished searches go back to the pool
+        if (phase == PH_OBJ && my_oi >= P.n_objects) {
+            WfPath<T>* dst = W.in + slot;                     // (t, object, primitive) share one 16-byte piece of the record
+            dst->hit_t = closest; dst->hit_obj = any_hit ? id.obj : WF_NO_HIT; dst->hit_prim = id.prim;
+            if (FEATS & F_MEDIUM) { dst->rng[0] = rng.s0; dst->rng[1] = rng.s1; dst->rng[2] = rng.s2; dst->rng[3] = rng.s3; }
+            slot = NONE; phase = PH_NEW;
+        }
+        // ---- idle lanes take the next live paths of the wave's batch
+        for (;;) {
+            const unsigned long long want = __ballot(phase == PH_NEW);
+            if (want == 0ull) break;
+            if (q_count == 0u) {
+                if (list_done) break;
+                const unsigned long long base64 = (unsigned long long)next_batch * 64ull;
+                if (base64 >= (unsigned long long)W.n_alive) { list_done = true; break; }
+                const uint32_t base = (uint32_t)base64;
+                next_batch += n_waves_grid;
+                q_count = W.n_alive - base < 64u ? W.n_alive - base : 64u;
+                q_head = 0;
+                batch_slot = lane < q_count ? base + lane : NONE;           // the pool is compact: positions [0, n_alive) are the live paths
+            }
+            const uint32_t n_want = (uint32_t)__popcll(want);
+            const uint32_t take = n_want < q_count ? n_want : q_count;
+            const uint32_t rank = lane_rank(want);
+            const uint32_t got = (uint32_t)__shfl((int)batch_slot, (int)((q_head + rank) & 63u), 64);
+            if (phase == PH_NEW && rank < take) {
+                slot = got;
+                const WfPath<T>* src = W.in + slot;
+                ray.o = mk<T>(src->o[0], src->o[1], src->o[2]);
+                ray.d = mk<T>(src->d[0], src->d[1], src->d[2]);
+                ray.tm = src->tm;
+                if (FEATS & F_MEDIUM) { rng.s0 = src->rng[0]; rng.s1 = src->rng[1]; rng.s2 = src->rng[2]; rng.s3 = src->rng[3]; }
+                phase = PH_OBJ; my_oi = 0; closest = Lim<T>::inf(); any_hit = false;
+            }
+            q_head += take; q_count -= take;
+        }
+        // ---- world.hit (main.rs:48), resumable: objects in push order from my_oi up to the next BVH object or the end
+        for (uint32_t oi = 0; oi < P.n_objects; oi++) {
+            const bool here = phase == PH_OBJ && my_oi == oi;
+            if (__ballot(here) == 0) continue;
+            const DObject ob = ld_obj(P.objects + oi);
+            if (here) {
+                if (ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0)) {
+                    phase = PH_BVH; tv_node = ob.geom_first; tv_sp = 0; tv_closest = closest; tv_any = false; tv_best = 0; tv_have_leaf = false;
+                    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), ray);
+                    inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
+                } else {
+                    object_hit<T, FEATS>(P, oi, ob, ray, TMin<T>::v(), rng, closest, id, any_hit, stack);
+                    my_oi = oi + 1u;
+                }
+            }
+        }
+        DIAG_ADD(1);
+    }
+    if (P.stats) {
+        unsigned long long* const st = stats_row(P.stats);
+        unsigned long long a = n_active, b = n_step_lanes;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
+        if (lane == 0) { atomicAdd(&st[1], n_iters); atomicAdd(&st[2], a); atomicAdd(&st[9], n_steps); atomicAdd(&st[10], b); }
+#ifdef RT_DIAG
+        if (lane == 0) for (int q = 0; q < 2; q++) atomicAdd(&st[3 + q], dg_sum[q]);
+#endif
+    }
+}
+
+// Hit record + material for every live path (main.rs:50-118), one thread each; `P.out` receives the radiance of finished paths.
+template <typename T, uint32_t FEATS>
+__global__ void __launch_bounds__(1024) wf_shade_kernel(const KParams<T> P, const WfParams<T> W) {
+    __shared__ uint32_t wave_live[16], wave_base[16];
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
+    const bool valid = i < W.n_alive;
+    uint32_t lp = 0, smp = 0;
+    bool done = false;
+    V3<T> L = mk<T>(T(0), T(0), T(0));
+    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
+    V3<T> beta = mk<T>(T(0), T(0), T(0));
+    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    uint32_t depth_left = 0;
+    if (valid) {
+        const WfPath<T> rec_in = wf_load(W.in + i);
+        ray.o = mk<T>(rec_in.o[0], rec_in.o[1], rec_in.o[2]);
+        ray.d = mk<T>(rec_in.d[0], rec_in.d[1], rec_in.d[2]);
+        ray.tm = rec_in.tm;
+        beta = mk<T>(rec_in.beta[0], rec_in.beta[1], rec_in.beta[2]);
+        rng.s0 = rec_in.rng[0]; rng.s1 = rec_in.rng[1]; rng.s2 = rec_in.rng[2]; rng.s3 = rec_in.rng[3];
+        depth_left = rec_in.depth;
+        lp = rec_in.px; smp = rec_in.smp;
+        V3<T> e = mk<T>(T(0), T(0), T(0));
+        if (depth_left == 0u) {
+            done = true;                                                            // main.rs:42-45 (max_depth 0)
+        } else {
+            HitId id; id.obj = rec_in.hit_obj; id.prim = rec_in.hit_prim;
+            if (id.obj == WF_NO_HIT) { e = ld3(P.background); done = true; }         // main.rs:118
+            else {
+                Rec<T> rec;
+                finalize_hit<T, FEATS>(P, ray, rec_in.hit_t, id, true, rec);
+                shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
+            }
+        }
+        if (done) L = beta * e;
+    }
+    // ---- survivors move to the OTHER pool, packed: the workgroup's survivors take consecutive positions (ONE atomic per workgroup
+    //      of 1024 paths: a single counter takes ~88 atomics per microsecond), so that the next round reads and writes the pool coalesced
+    const bool fin = valid && done, live = valid && !done;
+    {
+        const unsigned long long ml = __ballot(live);
+        if (lane == 0) wave_live[wave_in_block] = (uint32_t)__popcll(ml);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (uint32_t k = 0; k < 16u; k++) { wave_base[k] = tot; tot += wave_live[k]; }
+            const uint32_t b = tot ? atomicAdd(W.counters + 1, tot) : 0u;
+            for (uint32_t k = 0; k < 16u; k++) wave_base[k] += b;
+        }
+        __syncthreads();
+        const uint32_t bl = wave_base[wave_in_block];
+        if (live) {
+            const uint32_t o = bl + lane_rank(ml);
+            WfPath<T> r;
+            r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z; r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z; r.tm = ray.tm;
+            r.beta[0] = beta.x; r.beta[1] = beta.y; r.beta[2] = beta.z; r.hit_t = T(0);
+            r.rng[0] = rng.s0; r.rng[1] = rng.s1; r.rng[2] = rng.s2; r.rng[3] = rng.s3;
+            r.hit_obj = WF_NO_HIT; r.hit_prim = 0; r.px = lp; r.smp = smp; r.depth = depth_left;
+            wf_store(W.out + o, r);
+        }
+    }
+    // ---- finished paths hand in beta * e: lanes of the wave that share a pixel are summed first (fixed butterfly), one lane adds
+    double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
+    if (fin) {
+        if (!(l0 - l0 == 0.0 && l1 - l1 == 0.0 && l2 - l2 == 0.0)) atomicAdd(&P.stats[0], 1ull);
+        if (P.samples_out) { double* so = P.samples_out + ((size_t)lp * P.spp + smp) * 3u; so[0] = l0; so[1] = l1; so[2] = l2; }
+    }
+    unsigned long long m = __ballot(fin);
+    bool need = fin;
+    while (m) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
+        const uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)leader);
+        const bool mine = need && lp == px;
+        const double s0 = wave_sum(mine ? l0 : 0.0), s1 = wave_sum(mine ? l1 : 0.0), s2 = wave_sum(mine ? l2 : 0.0);
+        if (lane == leader) { double* o = P.out + (size_t)px * 3u; unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2); }
+        need = need && !mine;
+        m = __ballot(need);
+    }
+}
+
+template <typename T> hipError_t launch_wf_gen(const KParams<T>& P, const WfParams<T>& W, hipStream_t stream) {
+    if (W.n_new == 0u) return hipSuccess;
+    hipLaunchKernelGGL((wf_gen_kernel<T>), dim3((W.n_new + 255u) / 256u), dim3(256), 0, stream, P, W);
+    return hipGetLastError();
+}
+template <typename T> hipError_t launch_wf_trace(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
+    return dispatch<T>(scene_feats, P.flags & ~16u, [&]() { return hipErrorInvalidValue; },          // (list scenes have no wavefront form)
+        [&](auto feats) {
+            constexpr uint32_t F = decltype(feats)::value;
+            hipError_t e = shmem > 65536u ? hipFuncSetAttribute((const void*)wf_trace_kernel<T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) : hipSuccess;
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL((wf_trace_kernel<T, F>), dim3(n_blocks), dim3(Shape<F>::THREADS), shmem, stream, P, W);
+            return hipGetLastError();
+        });
+}
+template <typename T> hipError_t launch_wf_shade(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, hipStream_t stream) {
+    if (W.n_alive == 0u) return hipSuccess;
+    return dispatch<T>(scene_feats, P.flags & ~16u, [&]() { return hipErrorInvalidValue; },
+        [&](auto feats) {
+            hipLaunchKernelGGL((wf_shade_kernel<T, decltype(feats)::value>), dim3((W.n_alive + 1023u) / 1024u), dim3(1024), 0, stream, P, W);
+            return hipGetLastError();
+        });
+}
+template hipError_t launch_wf_gen<double>(const KParams<double>&, const WfParams<double>&, hipStream_t);
+template hipError_t launch_wf_gen<float>(const KParams<float>&, const WfParams<float>&, hipStream_t);
+template hipError_t launch_wf_trace<double>(const KParams<double>&, const WfParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);
+template hipError_t launch_wf_trace<float>(const KParams<float>&, const WfParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
+template hipError_t launch_wf_shade<double>(const KParams<double>&, const WfParams<double>&, uint32_t, hipStream_t);
+template hipError_t launch_wf_shade<float>(const KParams<float>&, const WfParams<float>&, uint32_t, hipStream_t);
+#endif
+
 } // namespace rt
 
 #if RT_TU != 1

@@ -20,4 +20,8 @@ static const size_t RT_STATS_BYTES = (size_t)RT_STATS_SLOTS * RT_STATS_ROWS * si
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
 // Resident blocks per CU for the instantiation that serves `scene_feats`.
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem);
+// Wavefront backend (BVH scenes, RT_WAVEFRONT): one round = gen, trace, shade (rt_kernel.hip)
+template <typename T> hipError_t launch_wf_gen(const KParams<T>& P, const WfParams<T>& W, hipStream_t stream);
+template <typename T> hipError_t launch_wf_trace(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
+template <typename T> hipError_t launch_wf_shade(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, hipStream_t stream);
 }

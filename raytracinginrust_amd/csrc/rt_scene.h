@@ -81,6 +81,7 @@ struct Scene {
         void* d_tiles = nullptr; size_t tiles_bytes = 0;
         void* d_gather = nullptr; size_t gather_bytes = 0;
         void* d_frame = nullptr; size_t frame_bytes = 0;
+        void* d_wf = nullptr; size_t wf_bytes = 0;                            // wavefront backend: the two path pools (RT_WAVEFRONT)
     };
     std::vector<DeviceCtx*> ctxs;          // created on first use of a device
     int last_device = -1;                  // device of the most recent launch (what rt_last_* report)

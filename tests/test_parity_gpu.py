@@ -676,3 +676,33 @@ def test_aabb_hit_on_the_device_against_the_oracle(pbe, obe):
     use = ((out & 4) != 0) & box_tame
     assert use.sum() > n // 2 and (~use).sum() > 100
     assert np.array_equal((out[use] >> 1) & 1, ref[use]), "the NaN-free form disagrees where it would be used"
+
+
+@pytest.mark.parametrize("name", ["random", "final", "teapot", "smoke"])
+def test_wavefront_backend_is_scheduling_only(name, pbe, earth, monkeypatch):
+    """RT_WAVEFRONT (opt-in, BVH scenes): the frame's paths go through a pool in HBM in rounds of three kernels (new camera paths /
+    world.hit with lanes that fetch the next path when their search ends / hit record + material) instead of one persistent kernel.
+    Per path the operations and their order are the megakernel's: every sample is bit-identical, the per-pixel sums differ only by the
+    order of the additions.  A small pool forces many rounds; list scenes ignore the flag."""
+    if name == "smoke":
+        b, cam, bg = scenes.cornell_box_with_smoke(pbe)         # media with box boundaries beside a list: no BVH -> flag ignored
+    else:
+        b, cam, bg = build_scene(name, pbe, earth)
+    W, H, spp, depth = 72, 40, 8, 30
+    ref, rs = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    n_bad = R.last_stats(b)["nonfinite_samples"]
+    for pool in ("16777216", "1000"):
+        monkeypatch.setenv("RT_WF_POOL", pool)
+        got, gs = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_WAVEFRONT, want_samples=True)
+        assert np.array_equal(rs.view(np.uint64), gs.view(np.uint64))
+        assert R.last_stats(b)["nonfinite_samples"] == n_bad
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(got)) and np.all(np.abs(got[fin] - ref[fin]) <= 1e-12 * (spp + np.abs(ref[fin])))
+    monkeypatch.delenv("RT_WF_POOL")
+    # sharded as on 3 GPUs: each rank's tiles through the wavefront backend equal the megakernel's
+    import torch
+    for rank in range(3):
+        a = D.TileRenderer(b, cam, bg, W, H, spp, depth, tile_px=64, rank=rank, world=3).render_local().clone()
+        c = D.TileRenderer(b, cam, bg, W, H, spp, depth, flags=R.RT_WAVEFRONT, tile_px=64, rank=rank, world=3).render_local().clone()
+        torch.cuda.synchronize()
+        assert torch.allclose(a, c, rtol=1e-12, atol=1e-12 * spp, equal_nan=True)

@@ -20,4 +20,4 @@ for key in os.environ.get('RT_WORKLOADS', 'C1,C2,C3,C4').split(','):
     tv = R.last_traversal_stats(b)
     trav = f"  adv {tv['advance_lanes']/max(1,64*tv['advance_passes']):.2f} x {tv['advance_passes']/1e6:.2f}M  trav {tv['traversal_lanes']/max(1,64*tv['traversal_steps']):.2f} x {tv['traversal_steps']/1e6:.1f}M" if tv['traversal_steps'] else ''
     print('   ', R.last_launch_info(b))
-    print(f'{key} {w.scene} {w.W}x{w.H} at {s} spp: {ms:9.2f} ms  {w.W*w.H*s/ms/1e3:8.1f} Msamples/s  lane util {st["live_lane_iterations"]/(64*st["wave_iterations"]):.3f}  -> full config ({w.spp} spp) ~ {ms*w.spp/s/1e3:.2f} s{trav}')
+    print(f'{key} {w.scene} {w.W}x{w.H} at {s} spp: {ms:9.2f} ms  {w.W*w.H*s/ms/1e3:8.1f} Msamples/s  lane util {st["live_lane_iterations"]/max(1,64*st["wave_iterations"]):.3f}  -> full config ({w.spp} spp) ~ {ms*w.spp/s/1e3:.2f} s{trav}')
