@@ -207,6 +207,8 @@ int rt_last_flush_count(rt_scene*, unsigned long long* out);
 /* Scenes with a BVH (persistent-traversal kernel): [0] advance passes, [1] lanes taking part in them, [2] traversal
  * steps, [3] lanes stepping, all summed over wavefronts ([3] / (64*[2]) = lane utilisation of the traversal). */
 int rt_last_traversal_stats(rt_scene*, unsigned long long out4[4]);
+/* Persistent-traversal kernels: of the traversal steps above, [0] the leaf steps (primitive tests) and [1] the lanes in them. */
+int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 /* Diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections (zeros in a normal build). */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out6[6]);
 /* Test aid: AABB::hit (src/aabb.rs:19-36) evaluated on the device for n (box, ray, [t_min, t_max]) triples given as host arrays

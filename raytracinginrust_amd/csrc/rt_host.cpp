@@ -790,6 +790,13 @@ int rt_last_traversal_stats(rt_scene* sc, unsigned long long out[4]) {
     out[0] = h[1]; out[1] = h[2]; out[2] = h[9]; out[3] = h[10];
     return 0;
 }
+// persistent-traversal kernels: {leaf steps, lanes in them} of the traversal steps above (the rest are box steps)
+int rt_last_leaf_steps(rt_scene* sc, unsigned long long out[2]) {
+    unsigned long long h[RT_STATS_SLOTS];
+    if (read_stats(sc, h)) return -1;
+    out[0] = h[12]; out[1] = h[13];
+    return 0;
+}
 // diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections; zeros otherwise
 int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[6]) {
     unsigned long long h[RT_STATS_SLOTS];

@@ -437,9 +437,12 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
             if (want_box) {
                 const DBvhNode<T> nd = fetch_node(P, node);
                 const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, closest) : box_inside_exact(nd, ray.o, inv, t_min, closest);
+                // The waiting nodes: the newest one in a register (`top`), the rest in the lane's LDS column.  A pop takes `top` at
+                // once and refills it from LDS — a read nobody waits for until the next pop — so the LDS round trip is off the
+                // node -> box test -> next node chain.
                 if (inside && !(nd.a & BVH_LEAF)) {
                     const bool right_first = near_first && get(ray.d, nd.a) < T(0);
-                    stack[sp * 64u] = right_first ? nd.c : nd.b;           // the other child waits (reference order: right waits)
+                    stack[sp * 64u] = right_first ? nd.c : nd.b;
                     sp++;
                     node = right_first ? nd.b : nd.c;
                 } else {
@@ -1200,10 +1203,7 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
     if (!stats) return;
     if (n_nonfinite) atomicAdd(&stats[0], (unsigned long long)n_nonfinite);
     if (n_flush) atomicAdd(&stats[11], (unsigned long long)n_flush);
-    unsigned long long a = n_active;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-    if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], a); }
+    if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], n_active); }      // (both wave-uniform: kept in scalar registers)
 }
 
 // ------------------------------------------------------------------ list scenes: lock-step bounce loop
@@ -1293,7 +1293,10 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     // ---- the queue is empty: hand in what is left
     flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
     unsigned long long* const st = stats_row(P.stats);
-    write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
+    unsigned long long live = n_active;                 // (per-lane here: a scalar count made this kernel's register allocation worse)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
+    write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
 #ifdef RT_DIAG
     if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
@@ -1340,7 +1343,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
     typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
     acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
-    unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0;
+    unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0, n_leaf_steps = 0, n_leaf_lanes = 0;   // steps: box steps
     DIAG_DECL
     DIAG_T0();
 
@@ -1367,27 +1370,26 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             uint32_t stop_below = n_bvh * 3u / 4u;                  // entered below trav_hi (nothing else to do): until a quarter has finished
             if (stop_below > P.trav_lo) stop_below = P.trav_lo;
             if (stop_below < 1u) stop_below = 1u;
+            // Two kinds of step, chosen by vote so that each runs with many lanes: a box step (lanes that hold a node: bbox test,
+            // descend / pop; a lane that reaches a leaf keeps it pending and waits) and a leaf step (lanes with a pending leaf:
+            // primitive tests).  Per lane the order bbox, left, right and the shrinking t_max are those of BVH::hit (bvh.rs:77-91) —
+            // a lane never walks on before its pending leaf has been tested.  The box steps are an inner loop of their own with
+            // nothing else in it (same shape as bvh_hit_ww's); a lane whose search ends just idles until the pass is over.
+            const bool act = phase == PH_BVH;
             for (;;) {
-                const bool act = phase == PH_BVH;
-                const uint32_t n = (uint32_t)__popcll(__ballot(act));
-                if (n < stop_below) break;
-                // Two kinds of step, chosen by vote so that each runs with many lanes: a box step (lanes that hold a node:
-                // bbox test, descend / pop; a lane that reaches a leaf keeps it pending and waits) and a leaf step (lanes
-                // with a pending leaf: primitive tests).  Per lane the order bbox, left, right and the shrinking t_max are
-                // those of BVH::hit (bvh.rs:77-91) — a lane never walks on before its pending leaf has been tested.
-                const bool want_leaf = act && tv_have_leaf;
-                const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
-                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
-                const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box));
-                n_steps++;
-                if (n_box != 0u && n_leaf * 64u < P.trav_leaf * n) {
+                bool few = false;
+                for (;;) {
+                    const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
+                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(act && tv_have_leaf));
+                    few = n_box + n_leaf < stop_below;
+                    if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
+                    n_steps++; n_step_lanes += n_box;
                     if (want_box) {
-                        n_step_lanes++;
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
                         if (inside && !(nd.a & BVH_LEAF)) {
                             const bool right_first = near_first && get(r.d, nd.a) < T(0);
-                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;              // the other child waits (reference order: right waits)
+                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;
                             tv_sp++;
                             tv_node = right_first ? nd.b : nd.c;
                         } else {
@@ -1397,21 +1399,23 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                             else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
                         }
                     }
-                } else if (n_leaf != 0u) {
-                    if (want_leaf) {
-                        n_step_lanes++;
-                        T t; uint32_t prim;
-                        if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, r, t_min, tv_closest, t, prim) &&
-                            bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
-                        tv_have_leaf = false;
-                    }
                 }
-                if (act && !tv_have_leaf && tv_node == BVH_DONE) {
-                    // ---- this BVH is done: its result joins the list search (hit.rs:62-69), the lane moves to the next object
-                    if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
-                    my_oi++;
-                    phase = PH_OBJ;
+                if (few) break;                                   // (pending leaves wait for the next traversal pass)
+                DIAG_ADD(0);
+                n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(act && tv_have_leaf));
+                if (act && tv_have_leaf) {
+                    T t; uint32_t prim;
+                    if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, r, t_min, tv_closest, t, prim) &&
+                        bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
+                    tv_have_leaf = false;
                 }
+                DIAG_ADD(5);
+            }
+            if (act && !tv_have_leaf && tv_node == BVH_DONE) {
+                // ---- this BVH is done: its result joins the list search (hit.rs:62-69), the lane moves to the next object
+                if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
+                my_oi++;
+                phase = PH_OBJ;
             }
             DIAG_ADD(0);
             continue;
@@ -1419,7 +1423,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
 
         // ================= advance pass
         n_iters++;
-        if (phase == PH_OBJ || phase == PH_SHADE) n_active++;
+        n_active += (unsigned long long)__popcll(__ballot(phase == PH_OBJ || phase == PH_SHADE));
         // ---- lanes whose list search is complete: the rest of the level (main.rs:50-118), then the child level starts
         if (phase == PH_OBJ && my_oi >= P.n_objects) phase = PH_SHADE;
         if (phase == PH_SHADE) {
@@ -1479,10 +1483,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
     unsigned long long* const st = stats_row(P.stats);
     write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
     if (st) {
-        unsigned long long a = n_step_lanes;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-        if (lane == 0) { atomicAdd(&st[9], n_steps); atomicAdd(&st[10], a); }
+        if (lane == 0) { atomicAdd(&st[9], n_steps + n_leaf_steps); atomicAdd(&st[10], n_step_lanes + n_leaf_lanes); atomicAdd(&st[12], n_leaf_steps); atomicAdd(&st[13], n_leaf_lanes); }
 #ifdef RT_DIAG
         if (lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
@@ -1767,7 +1768,7 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
 
         // ================= hand-over pass
         n_iters++;
-        if (phase == PH_OBJ || phase == PH_NEW) n_active++;
+        n_active += (unsigned long long)__popcll(__ballot(phase == PH_OBJ || phase == PH_NEW));
         // ---- finished searches go back to the pool
         if (phase == PH_OBJ && my_oi >= P.n_objects) {
             WfPath<T>* dst = W.in + slot;                     // (t, object, primitive) share one 16-byte piece of the record
@@ -1824,10 +1825,10 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     }
     if (P.stats) {
         unsigned long long* const st = stats_row(P.stats);
-        unsigned long long a = n_active, b = n_step_lanes;
+        unsigned long long b = n_step_lanes;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off, 64); b += __shfl_xor(b, off, 64); }
-        if (lane == 0) { atomicAdd(&st[1], n_iters); atomicAdd(&st[2], a); atomicAdd(&st[9], n_steps); atomicAdd(&st[10], b); }
+        for (int off = 32; off >= 1; off >>= 1) b += __shfl_xor(b, off, 64);
+        if (lane == 0) { atomicAdd(&st[1], n_iters); atomicAdd(&st[2], n_active); atomicAdd(&st[9], n_steps); atomicAdd(&st[10], b); }
 #ifdef RT_DIAG
         if (lane == 0) for (int q = 0; q < 2; q++) atomicAdd(&st[3 + q], dg_sum[q]);
 #endif
@@ -1914,6 +1915,7 @@ __global__ void __launch_bounds__(1024) wf_shade_kernel(const KParams<T> P, cons
     }
 }
 
+#if !defined(RT_KRES_ONLY)
 template <typename T> hipError_t launch_wf_gen(const KParams<T>& P, const WfParams<T>& W, hipStream_t stream) {
     if (W.n_new == 0u) return hipSuccess;
     hipLaunchKernelGGL((wf_gen_kernel<T>), dim3((W.n_new + 255u) / 256u), dim3(256), 0, stream, P, W);
@@ -1943,6 +1945,7 @@ template hipError_t launch_wf_trace<double>(const KParams<double>&, const WfPara
 template hipError_t launch_wf_trace<float>(const KParams<float>&, const WfParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
 template hipError_t launch_wf_shade<double>(const KParams<double>&, const WfParams<double>&, uint32_t, hipStream_t);
 template hipError_t launch_wf_shade<float>(const KParams<float>&, const WfParams<float>&, uint32_t, hipStream_t);
+#endif
 #endif
 
 } // namespace rt

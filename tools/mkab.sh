@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/../raytracinginrust_amd/csrc"
 name=$1; f1=$2; f2=$3; src=${4:-rt_kernel.hip}
 mkdir -p ab
-BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 -I."
+BASE="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function --offload-arch=gfx950 -I. -mllvm -disable-machine-licm"   # as the Makefile
 /opt/rocm/bin/hipcc $BASE -mllvm -enable-misched=0 $f1 -DRT_TU=1 -c $src -o ab/${name}_lean.o &
 /opt/rocm/bin/hipcc $BASE $f2 -DRT_TU=2 -c $src -o ab/${name}_rest.o &
 wait
