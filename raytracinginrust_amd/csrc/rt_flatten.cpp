@@ -369,13 +369,16 @@ struct Flattener {
 void relayout_bvh_by_depth(HostFlat& f) {
     const size_t n = f.bvh.size();
     if (n == 0) return;
-    std::vector<uint32_t> depth(n, 0xFFFFFFFFu);
-    std::vector<std::pair<uint32_t, uint32_t>> todo;          // (preorder id, depth)
-    for (const DObject& ob : f.objects) if (ob.geom_kind == G_BVH) todo.push_back({ob.geom_first, 0u});
+    const uint32_t DONE = 0xFFFFFFFFu;
+    std::vector<uint32_t> depth(n, DONE), skip(n, DONE);      // skip: where BVH::hit's recursion goes once this subtree is finished or culled
+    struct Todo { uint32_t i, d, skip; };
+    std::vector<Todo> todo;                                   // (preorder id, depth, skip link)
+    for (const DObject& ob : f.objects) if (ob.geom_kind == G_BVH) todo.push_back({ob.geom_first, 0u, DONE});
     while (!todo.empty()) {
-        const auto [i, d] = todo.back(); todo.pop_back();
-        depth[i] = d;
-        if (!(f.bvh[i].a & BVH_LEAF)) { todo.push_back({f.bvh[i].b, d + 1u}); todo.push_back({i + 1u, d + 1u}); }
+        const Todo t = todo.back(); todo.pop_back();
+        depth[t.i] = t.d; skip[t.i] = t.skip;
+        // left child (preorder successor): when it is done the right child is next; right child: whatever follows the parent
+        if (!(f.bvh[t.i].a & BVH_LEAF)) { todo.push_back({f.bvh[t.i].b, t.d + 1u, t.skip}); todo.push_back({t.i + 1u, t.d + 1u, f.bvh[t.i].b}); }
     }
     std::vector<uint32_t> order(n), new_id(n);
     for (size_t i = 0; i < n; i++) order[i] = (uint32_t)i;
@@ -384,7 +387,7 @@ void relayout_bvh_by_depth(HostFlat& f) {
     std::vector<DBvhNode<double>> out(n);
     for (size_t i = 0; i < n; i++) {
         DBvhNode<double> nd = f.bvh[i];
-        nd.pad = 0;
+        nd.skip = skip[i] == DONE ? DONE : new_id[skip[i]];
         if (nd.a & BVH_LEAF) nd.c = (uint32_t)i;
         else { nd.c = new_id[i + 1]; nd.b = new_id[nd.b]; }
         out[new_id[i]] = nd;

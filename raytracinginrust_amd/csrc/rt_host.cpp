@@ -354,7 +354,7 @@ template <typename T> void cv(const DSphere<double>& a, DSphere<T>& b) { for (in
 template <typename T> void cv(const DMSphere<double>& a, DMSphere<T>& b) { for (int k = 0; k < 3; k++) { b.c0[k] = (T)a.c0[k]; b.c1[k] = (T)a.c1[k]; } b.t0 = (T)a.t0; b.t1 = (T)a.t1; b.r = (T)a.r; b.mat = a.mat; b.pad = 0; }
 template <typename T> void cv(const DTri<double>& a, DTri<T>& b) { for (int k = 0; k < 3; k++) { b.v0[k] = (T)a.v0[k]; b.e1[k] = (T)a.e1[k]; b.e2[k] = (T)a.e2[k]; } b.mat = a.mat; b.pad = 0; }
 template <typename T> void cv(const DOp<double>& a, DOp<T>& b) { b.kind = a.kind; b.axis = a.axis; b.x = (T)a.x; b.y = (T)a.y; b.z = (T)a.z; }
-template <typename T> void cv(const DBvhNode<double>& a, DBvhNode<T>& b) { for (int k = 0; k < 3; k++) { b.mn[k] = (T)a.mn[k]; b.mx[k] = (T)a.mx[k]; } b.a = a.a; b.b = a.b; b.c = a.c; b.pad = 0; }
+template <typename T> void cv(const DBvhNode<double>& a, DBvhNode<T>& b) { for (int k = 0; k < 3; k++) { b.mn[k] = (T)a.mn[k]; b.mx[k] = (T)a.mx[k]; } b.a = a.a; b.b = a.b; b.c = a.c; b.skip = a.skip; }
 template <typename T> void cv(const DMaterial<double>& a, DMaterial<T>& b) { b.kind = a.kind; b.tex = a.tex; for (int k = 0; k < 3; k++) b.albedo[k] = (T)a.albedo[k]; b.param = (T)a.param; }
 template <typename T> void cv(const DTexture<double>& a, DTexture<T>& b) { b.kind = a.kind; b.a = a.a; b.b = a.b; b.c = a.c; for (int k = 0; k < 3; k++) b.color[k] = (T)a.color[k]; b.scale = (T)a.scale; }
 template <typename T> void cv(const DPbr<double>& a, DPbr<T>& b) {
@@ -393,10 +393,10 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DBvhNode<T>>(f.bvh, d.bvh)) return -1;
     {   // field-wise copy of the nodes (a few KB; only the RT_NODE_SOA measurement build reads it)
         const size_t n = f.bvh.size();
-        std::vector<T> soa((6 * n + 2 * n) + 8, T(0));                  // u32 a, b, c packed behind the bounds (3n u32 <= 2n reals for f32, 1.5n for f64)
+        std::vector<T> soa((6 * n + 4 * n) + 8, T(0));                  // u32 a, b, c, skip packed behind the bounds (4n u32 = 4n reals for f32, 2n for f64)
         for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) { soa[(size_t)k * n + i] = (T)f.bvh[i].mn[k]; soa[(size_t)(3 + k) * n + i] = (T)f.bvh[i].mx[k]; }
         uint32_t* u = (uint32_t*)(soa.data() + 6 * n);
-        for (size_t i = 0; i < n; i++) { u[i] = f.bvh[i].a; u[n + i] = f.bvh[i].b; u[2 * n + i] = f.bvh[i].c; }
+        for (size_t i = 0; i < n; i++) { u[i] = f.bvh[i].a; u[n + i] = f.bvh[i].b; u[2 * n + i] = f.bvh[i].c; u[3 * n + i] = f.bvh[i].skip; }
         if (upload_raw(soa, d.bvh_soa)) return -1;
     }
     if (upload_vec<DMaterial<T>>(f.materials, d.materials)) return -1;
@@ -457,6 +457,9 @@ static int acquire_slot(Scene& s, Scene::DeviceCtx& c, hipStream_t stream, Scene
 // Loop shape for mesh scenes (same samples either way): a triangle-mesh BVH that stands beside other top-level objects is
 // entered by a minority of the rays, which is where persistent traversal pays (measured +20 % on the teapot room); when
 // every ray walks the BVH (the BVH is the world) the lock-step loop is faster.
+// LDS traversal stack entries per lane: none in the reference's left-then-right order (skip links, rt_ir.h DBvhNode), the tree's depth
+// when children are visited nearer-first
+static uint32_t stack_depth_of(const HostFlat& f, uint32_t effective) { return ((effective & RT_NEAR_FIRST_BVH) && (f.feats & F_BVH)) ? f.bvh_depth : 0u; }
 static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
     uint32_t out = flags;
     if (!(flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) && (f.feats & F_BVH) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) == 0u) {
@@ -519,6 +522,7 @@ int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const
     W.P = Pn;
     auto bind = [&](int cur) { W.in = pools[cur]; W.out = pools[cur ^ 1]; };
     // LDS of the trace kernel: the top of the BVH beside the waves' stacks (no camera-path queues here)
+    P.stack_depth = f.bvh_depth;                   // (this backend's trace kernel walks with the explicit stack in either order)
     const size_t waves = shape.threads / 64u, stacks = waves * (size_t)P.stack_depth * 256u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor; if (lds_total < 65536u) lds_total = 65536u;
     size_t room = lds_total > stacks ? (lds_total - stacks) / sizeof(DBvhNode<T>) : 0;
@@ -571,8 +575,6 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
-    P.stack_depth = f.bvh_depth;
-    if (const char* v = std::getenv("RT_STACK_DEPTH_MIN")) { const long n = std::strtol(v, nullptr, 10); if (n > (long)P.stack_depth && n <= RT_MAX_BVH_DEPTH) P.stack_depth = (uint32_t)n; }   // A/B runs only
     {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
         const double big = sizeof(T) == 8 ? 1e300 : 1e30;
         bool tame = f.bvh_tame;
@@ -588,6 +590,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     }
     P.cam.lens_radius = (T)cam.lens_radius; P.cam.time0 = (T)cam.time0; P.cam.time1 = (T)cam.time1;
     P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = effective_flags(f, flags);
+    P.stack_depth = stack_depth_of(f, P.flags);
     P.tile_px = tile_px; P.rank = rank; P.world = world;
     P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
     P.trav_hi = s.trav_hi; P.trav_lo = s.trav_lo; P.trav_leaf = s.trav_leaf;
@@ -709,8 +712,9 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     const LaunchShape shape = pathtrace_shape(s.flat.feats, eff);
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, cp->device));
     int bpc;
-    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<float>(shape, s.flat, prop, s.flat.bvh_depth), sizeof(DBvhNode<float>)));
-    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, s.flat.bvh_depth, cached_nodes<double>(shape, s.flat, prop, s.flat.bvh_depth), sizeof(DBvhNode<double>)));
+    const uint32_t sd = stack_depth_of(s.flat, eff);
+    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), sizeof(DBvhNode<float>)));
+    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd), sizeof(DBvhNode<double>)));
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;

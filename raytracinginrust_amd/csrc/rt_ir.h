@@ -59,7 +59,7 @@ template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; u
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
 struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
-template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, pad; };       // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
+template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 template <typename T> struct alignas(16) DMaterial { uint32_t kind, tex; T albedo[3]; T param; };   // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
 template <typename T> struct alignas(16) DTexture { uint32_t kind, a, b, c; T color[3]; T scale; }; // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height

@@ -330,8 +330,10 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
 }
 
 // BVH::hit, bvh.rs:77-91: bbox test, then left subtree, then right subtree with t_max shrunk to the left hit.
-// The recursion's t_max at any node equals min(original t_max, closest hit found earlier in DFS order), so one
-// running `closest` with an explicit stack (staged in LDS, one dword column per lane) is the same search.
+// The recursion's t_max at any node equals min(original t_max, closest hit found earlier in DFS order), so one running
+// `closest` over the same sequence of nodes is the same search.  In the reference's fixed order that sequence needs no stack:
+// every node carries a skip link (rt_ir.h) — the node the recursion reaches next when this node's subtree is finished or culled.
+// (Nearer-first order, opt-in, depends on the ray and keeps an explicit stack in LDS, one dword column per lane.)
 // AABB::hit (aabb.rs:19-36) recomputes 1/d per node; the value is the same every time, so it is hoisted.
 // In the reference's left-then-right order a later leaf with t <= t_max replaces an earlier one (hit.rs:62, bvh.rs:81-84).
 // When children are visited nearer-first (RT_NEAR_FIRST_BVH) the same winner is kept by letting an exact tie go to the leaf
@@ -402,7 +404,7 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
     const uint32_t n = P.n_bvh;
     for (uint32_t k = 0; k < 3u; k++) { nd.mn[k] = cl(P.bvh_soa + k * n + node); nd.mx[k] = cl(P.bvh_soa + (3u + k) * n + node); }
     const uint32_t* u = (const uint32_t*)(P.bvh_soa + 6u * n);
-    nd.a = cl(u + node); nd.b = cl(u + n + node); nd.c = cl(u + 2u * n + node); nd.pad = 0;
+    nd.a = cl(u + node); nd.b = cl(u + n + node); nd.c = cl(u + 2u * n + node); nd.skip = cl(u + 3u * n + node);
     return nd;
 #else
     return ld_node_at(P.bvh, node);
@@ -440,9 +442,14 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                 // The waiting nodes: the newest one in a register (`top`), the rest in the lane's LDS column.  A pop takes `top` at
                 // once and refills it from LDS — a read nobody waits for until the next pop — so the LDS round trip is off the
                 // node -> box test -> next node chain.
-                if (inside && !(nd.a & BVH_LEAF)) {
-                    const bool right_first = near_first && get(ray.d, nd.a) < T(0);
-                    stack[sp * 64u] = right_first ? nd.c : nd.b;
+                if (!near_first) {
+                    // reference order (left, then right): a threaded preorder walk — into the left child on a hit of an inner node,
+                    // otherwise along the node's skip link (the node the recursion would reach next).  No stack.
+                    if (inside && (nd.a & BVH_LEAF)) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; leaf_node = nd.c; }
+                    node = (inside && !(nd.a & BVH_LEAF)) ? nd.c : nd.skip;
+                } else if (inside && !(nd.a & BVH_LEAF)) {
+                    const bool right_first = get(ray.d, nd.a) < T(0);
+                    stack[sp * 64u] = right_first ? nd.c : nd.b;           // the farther child waits
                     sp++;
                     node = right_first ? nd.b : nd.c;
                 } else {
@@ -1387,9 +1394,12 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                     if (want_box) {
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
-                        if (inside && !(nd.a & BVH_LEAF)) {
-                            const bool right_first = near_first && get(r.d, nd.a) < T(0);
-                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;
+                        if (!near_first) {                                    // threaded preorder walk (bvh_hit_ww)
+                            if (inside && (nd.a & BVH_LEAF)) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = nd.c; }
+                            tv_node = (inside && !(nd.a & BVH_LEAF)) ? nd.c : nd.skip;
+                        } else if (inside && !(nd.a & BVH_LEAF)) {
+                            const bool right_first = get(r.d, nd.a) < T(0);
+                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;       // the farther child waits
                             tv_sp++;
                             tv_node = right_first ? nd.b : nd.c;
                         } else {
@@ -1958,7 +1968,7 @@ __global__ void aabb_kat_kernel(uint32_t n, const double* boxes, const double* r
     if (i >= n) return;
     DBvhNode<double> nd;
     for (int k = 0; k < 3; k++) { nd.mn[k] = boxes[i * 6 + k]; nd.mx[k] = boxes[i * 6 + 3 + k]; }
-    nd.a = nd.b = nd.c = nd.pad = 0;
+    nd.a = nd.b = nd.c = nd.skip = 0;
     const V3<double> o = mk<double>(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
     const V3<double> d = mk<double>(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     const V3<double> inv = mk<double>(1.0 / d.x, 1.0 / d.y, 1.0 / d.z);
