@@ -52,7 +52,7 @@ struct Scene {
     std::vector<DPbr<double>> pbr;
     std::vector<uint8_t> image_bytes;
     int world = -1;
-    unsigned trav_hi = 40, trav_lo = 24, trav_leaf = 16;      // persistent-traversal schedule (rt_scene_set_traversal_schedule); measured best on the teapot room
+    unsigned trav_hi = 40, trav_lo = 24, trav_leaf = 24;      // persistent-traversal schedule (rt_scene_set_traversal_schedule); measured best on the teapot room
     int bvh_builder = 0;      // 0: the reference's widest-axis object-median split (bvh.rs:18-73); 1: binned SAH (opt-in)
     std::vector<int> lights;
     std::string error;
