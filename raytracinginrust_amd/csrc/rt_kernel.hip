@@ -36,6 +36,12 @@
 #ifndef RT_TU
 #define RT_TU 0
 #endif
+#ifndef RT_BOX_STEPS             // box steps per box/leaf vote in the reference-order BVH loops (A/B in one process, % over one step per
+#define RT_BOX_STEPS 3           // vote: 2 steps random spheres +8.5, final scene +4.9; 3: +9.1 / +6.3; 4: +9.3 / +4.3)
+#endif
+#ifndef RT_BOX_STEPS_PERSIST     // ... and in the persistent loop (teapot room: 2 +0.5 %, 3 +1.9 %, 4 +6.6 %)
+#define RT_BOX_STEPS_PERSIST 4
+#endif
 #ifndef RT_SHARED_DIV3
 #define RT_SHARED_DIV3 (RT_TU == 2)
 #endif
@@ -436,12 +442,9 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
             const bool want_box = node != DONE && !have_leaf;
             const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
             if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
-            if (want_box) {
+            auto box_step = [&]() {
                 const DBvhNode<T> nd = fetch_node(P, node);
                 const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, closest) : box_inside_exact(nd, ray.o, inv, t_min, closest);
-                // The waiting nodes: the newest one in a register (`top`), the rest in the lane's LDS column.  A pop takes `top` at
-                // once and refills it from LDS — a read nobody waits for until the next pop — so the LDS round trip is off the
-                // node -> box test -> next node chain.
                 if (!near_first) {
                     // reference order (left, then right): a threaded preorder walk — into the left child on a hit of an inner node,
                     // otherwise along the node's skip link (the node the recursion would reach next).  No stack.
@@ -457,6 +460,13 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                     if (sp == 0) node = DONE;
                     else { sp--; node = stack[sp * 64u]; }
                 }
+            };
+            if (want_box) box_step();
+            // further box steps under the same vote (the vote is ~30 scalar instructions and two ballots: *measured* with two steps
+            // per vote random spheres +8 %, final scene +4 %); a lane that reached a leaf or the end sits them out
+            if (!near_first) {
+#pragma unroll
+                for (int k = 1; k < RT_BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
             }
         }
         if (have_leaf) {
@@ -1391,7 +1401,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                     few = n_box + n_leaf < stop_below;
                     if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
                     n_steps++; n_step_lanes += n_box;
-                    if (want_box) {
+                    auto box_step = [&]() {
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
                         if (!near_first) {                                    // threaded preorder walk (bvh_hit_ww)
@@ -1407,6 +1417,15 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                             // this node is finished (culled, or a leaf now pending): the next one comes off the stack
                             if (tv_sp == 0u) tv_node = BVH_DONE;
                             else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
+                        }
+                    };
+                    if (want_box) box_step();
+                    if (!near_first) {                                            // more box steps under the same vote (bvh_hit_ww)
+#pragma unroll
+                        for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {
+                            const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
+                            n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
+                            if (more) box_step();
                         }
                     }
                 }
