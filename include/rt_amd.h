@@ -209,8 +209,9 @@ int rt_last_flush_count(rt_scene*, unsigned long long* out);
 int rt_last_traversal_stats(rt_scene*, unsigned long long out4[4]);
 /* Persistent-traversal kernels: of the traversal steps above, [0] the leaf steps (primitive tests) and [1] the lanes in them. */
 int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
-/* Diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections (zeros in a normal build). */
-int rt_debug_section_cycles(rt_scene*, unsigned long long out6[6]);
+/* Diagnostic builds (-DRT_DIAG) only (zeros in a normal build): [0..5] wave-cycle sums of the six kernel sections, [6] rect tests
+ * counted per wavefront, [7] those among them in which no lane's plane distance lay in [t_min, closest]. */
+int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
 /* Test aid: AABB::hit (src/aabb.rs:19-36) evaluated on the device for n (box, ray, [t_min, t_max]) triples given as host arrays
  * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
  * traversal uses for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300).  Non-zero on a HIP error. */

@@ -801,11 +801,13 @@ int rt_last_leaf_steps(rt_scene* sc, unsigned long long out[2]) {
     out[0] = h[12]; out[1] = h[13];
     return 0;
 }
-// diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections; zeros otherwise
-int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[6]) {
+// diagnostic builds (-DRT_DIAG) only: wave-cycle sums of the six kernel sections; [6] wave-level rect tests, [7] those in which no
+// lane's t lay in [t_min, closest]; zeros otherwise
+int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[8]) {
     unsigned long long h[RT_STATS_SLOTS];
     if (read_stats(sc, h)) return -1;
     for (int k = 0; k < 6; k++) out[k] = h[3 + k];
+    out[6] = h[14]; out[7] = h[15];
     return 0;
 }
 

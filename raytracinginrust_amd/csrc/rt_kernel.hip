@@ -312,6 +312,15 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
             const DRect<T> nxt = ld_rect(P.rects + i + 1);
             __builtin_amdgcn_sched_barrier(0);
             T t;
+#ifdef RT_DIAG      // how often a rect test could be skipped for the whole wave by a filter on t: stats[14] tests, [15] with no lane in range
+            if (P.stats) {
+                const T tk = cur.plane == 2u ? (cur.k - ray.o.x) / ray.d.x : (cur.plane == 1u ? (cur.k - ray.o.y) / ray.d.y : (cur.k - ray.o.z) / ray.d.z);
+                const bool in_range = !(tk < t_min || tk > closest);
+                const unsigned long long m = __ballot(in_range);
+                const unsigned long long ex = __ballot(true);
+                if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)) == 0u) { atomicAdd(&P.stats[14], 1ull); if (m == 0ull) atomicAdd(&P.stats[15], 1ull); }
+            }
+#endif
             if (rect_test(cur, ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
             cur = nxt;
         }

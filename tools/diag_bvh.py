@@ -13,7 +13,7 @@ for key in os.environ.get('RT_WORKLOADS', 'C4').split(','):
     w = workloads.WORKLOADS[key]
     b, cam, bg = workloads.build(w, be, earth)
     R.render(b, cam, bg, w.W, w.H, 32, w.max_depth, flags=flags)
-    cyc = (C.c_ulonglong * 6)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
+    cyc = (C.c_ulonglong * 8)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
     tv = R.last_traversal_stats(b); tot = sum(cyc[:6])
     lf = (C.c_ulonglong * 2)(); be.lib.rt_last_leaf_steps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_last_leaf_steps(b.h, lf)
     nb, nl = tv['traversal_steps'] - lf[0], lf[0]
