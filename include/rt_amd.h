@@ -212,6 +212,11 @@ int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 /* Diagnostic builds (-DRT_DIAG) only (zeros in a normal build): [0..5] wave-cycle sums of the six kernel sections, [6] rect tests
  * counted per wavefront, [7] those among them in which no lane's plane distance lay in [t_min, closest]. */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
+/* Test aid (host only, no GPU): the flattened BVH's link words, out[4*i..] = node i's {a, b, c, skip}: `a` bit 31 marks a leaf (then kind
+ * and first primitive; b = count, c = the leaf's rank in the reference's depth-first order), otherwise a = split axis, b = right child,
+ * c = left child; skip = the node BVH::hit's recursion (src/bvh.rs:77-91) reaches next once this node's subtree is finished or culled
+ * (0xFFFFFFFF: the search is over).  roots_out: root node of every BVH object of the world list.  Returns the node count or -1. */
+int rt_debug_bvh_links(rt_scene*, uint32_t* out, uint32_t max_nodes, uint32_t* roots_out, uint32_t max_roots, uint32_t* n_roots_out);
 /* Test aid: AABB::hit (src/aabb.rs:19-36) evaluated on the device for n (box, ray, [t_min, t_max]) triples given as host arrays
  * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
  * traversal uses for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300).  Non-zero on a HIP error. */

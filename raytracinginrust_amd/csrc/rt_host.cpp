@@ -336,6 +336,19 @@ int rt_scene_flatten(rt_scene* sc, uint32_t counts[12]) {
     return 0;
 }
 
+// Test aid (host only): the flattened BVH's link words.  out[4*i ..] = node i's {a, b, c, skip} (rt_ir.h DBvhNode); roots_out receives
+// the root node of every BVH object in list order (at most max_roots).  Returns the number of nodes, or -1.
+int rt_debug_bvh_links(rt_scene* sc, uint32_t* out, uint32_t max_nodes, uint32_t* roots_out, uint32_t max_roots, uint32_t* n_roots_out) {
+    if (!sc) return -1;
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    const HostFlat& f = sc->s.flat;
+    if (out) for (size_t i = 0; i < f.bvh.size() && i < max_nodes; i++) { out[4 * i] = f.bvh[i].a; out[4 * i + 1] = f.bvh[i].b; out[4 * i + 2] = f.bvh[i].c; out[4 * i + 3] = f.bvh[i].skip; }
+    uint32_t n_roots = 0;
+    for (const DObject& ob : f.objects) if (ob.geom_kind == G_BVH) { if (roots_out && n_roots < max_roots) roots_out[n_roots] = ob.geom_first; n_roots++; }
+    if (n_roots_out) *n_roots_out = n_roots;
+    return (int)f.bvh.size();
+}
+
 uint32_t rt_local_tiles(uint32_t W, uint32_t H, uint32_t tile_px, uint32_t rank, uint32_t world) {
     (void)rank;
     if (tile_px == 0 || world == 0) return 0;
@@ -613,7 +626,10 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         LaunchShape wide = shape; wide.queue_entries = q;
         if (cached_nodes<T>(wide, f, prop, P.stack_depth) == P.n_cached) { shape = wide; break; }
     }
-    if (const char* v = std::getenv("RT_QUEUE_ENTRIES")) { const long n = std::strtol(v, nullptr, 10); if (n == 16 || n == 32 || n == 64) shape.queue_entries = (uint32_t)n; }   // A/B runs only
+    if (const char* v = std::getenv("RT_QUEUE_ENTRIES")) {       // A/B runs only: the queue first, the node cache gets what is left
+        const long n = std::strtol(v, nullptr, 10);
+        if (n == 16 || n == 32 || n == 64) { shape.queue_entries = (uint32_t)n; P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth); }
+    }
     P.queue_entries = shape.queue_entries;
     size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);

@@ -247,3 +247,39 @@ def test_jpeg_restart_intervals(tmp_path):
     ours = np.frombuffer(data, dtype=np.uint8).reshape(h, w, 3).astype(int)
     ref = np.asarray(Image.open(p).convert("RGB")).astype(int)
     assert np.abs(ours - ref).max() <= 3
+
+
+@pytest.mark.parametrize("name", ["random", "final", "teapot"])
+def test_bvh_skip_links_thread_the_recursions_order(name, pbe, earth):
+    """The kernels walk a BVH in the reference's order without a stack: `node = hit && inner ? left : skip` (rt_kernel.hip bvh_hit_ww).
+    For ANY pattern of box-test outcomes that walk must meet the nodes BVH::hit's recursion meets (src/bvh.rs:77-91: bbox, left, right),
+    in the same order.  Checked on the flattened trees of the shipped scenes with all-hit, all-miss and random outcome patterns."""
+    be = pbe
+    b, _, _ = build_scene(name, pbe, earth)
+    n = R.flatten(b)["bvh_nodes"]
+    links = (C.c_uint32 * (4 * n))(); roots = (C.c_uint32 * 8)(); n_roots = C.c_uint32(0)
+    be.lib.rt_debug_bvh_links.restype = C.c_int
+    be.lib.rt_debug_bvh_links.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
+    assert be.lib.rt_debug_bvh_links(b.h, links, n, roots, 8, C.byref(n_roots)) == n
+    L = np.frombuffer(links, np.uint32).reshape(n, 4)
+    LEAF, DONE = 1 << 31, 0xFFFFFFFF
+    assert n_roots.value >= 1
+    seen = np.zeros(n, bool)
+    for root in list(roots)[:n_roots.value]:
+        assert L[root, 3] == DONE
+        for trial in range(4):
+            rng = np.random.default_rng(trial)
+            hit = {0: np.ones(n, bool), 1: np.zeros(n, bool)}.get(trial, rng.random(n) < (0.5 if trial == 2 else 0.9))
+            want = []                                             # the recursion, iteratively: bbox test, then left, then right
+            todo = [int(root)]
+            while todo:
+                i = todo.pop(); want.append(i)
+                if hit[i] and not (L[i, 0] & LEAF): todo.append(int(L[i, 1])); todo.append(int(L[i, 2]))
+            got, i = [], int(root)                                # the kernels' threaded walk
+            while i != DONE:
+                got.append(i)
+                i = int(L[i, 2]) if (hit[i] and not (L[i, 0] & LEAF)) else int(L[i, 3])
+                assert len(got) <= n
+            assert got == want
+            if trial == 0: seen[got] = True
+    assert seen.all()                                             # every node belongs to exactly the trees walked
