@@ -1414,8 +1414,10 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
                         if (!near_first) {                                    // threaded preorder walk (bvh_hit_ww)
-                            if (inside && (nd.a & BVH_LEAF)) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = nd.c; }
-                            tv_node = (inside && !(nd.a & BVH_LEAF)) ? nd.c : nd.skip;
+                            // a leaf whose box is hit stays the lane's node until the leaf step has tested it: its record is read again
+                            // there (one more LDS read per leaf) instead of riding through the box steps in three registers
+                            if (inside && (nd.a & BVH_LEAF)) tv_have_leaf = true;
+                            else tv_node = inside ? nd.c : nd.skip;
                         } else if (inside && !(nd.a & BVH_LEAF)) {
                             const bool right_first = get(r.d, nd.a) < T(0);
                             stack[tv_sp * 64u] = right_first ? nd.c : nd.b;       // the farther child waits
@@ -1443,7 +1445,11 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(act && tv_have_leaf));
                 if (act && tv_have_leaf) {
                     T t; uint32_t prim;
-                    if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, r, t_min, tv_closest, t, prim) &&
+                    if (!near_first) {
+                        const DBvhNode<T> lf = fetch_node(P, tv_node);
+                        if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; }
+                        tv_node = lf.skip;
+                    } else if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, r, t_min, tv_closest, t, prim) &&
                         bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
                     tv_have_leaf = false;
                 }
