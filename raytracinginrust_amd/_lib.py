@@ -60,6 +60,10 @@ def load_path(path: str) -> Backend:
     lib.rt_last_flush_count.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
     lib.rt_last_traversal_stats.restype = C.c_int
     lib.rt_last_traversal_stats.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.rt_last_leaf_steps.restype = C.c_int
+    lib.rt_last_leaf_steps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+    lib.rt_debug_bvh_links.restype = C.c_int
+    lib.rt_debug_bvh_links.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rt_scene_set_traversal_schedule.restype = C.c_int
     lib.rt_scene_set_traversal_schedule.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
     lib.rt_scene_set_bvh_builder.restype = C.c_int

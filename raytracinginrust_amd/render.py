@@ -145,7 +145,11 @@ def last_traversal_stats(b: SceneBuilder) -> dict:
     out = (C.c_ulonglong * 4)()
     if be.lib.rt_last_traversal_stats(b.h, out) != 0:
         raise RenderError(_err(be))
-    return {"advance_passes": out[0], "advance_lanes": out[1], "traversal_steps": out[2], "traversal_lanes": out[3]}
+    leaf = (C.c_ulonglong * 2)()
+    if be.lib.rt_last_leaf_steps(b.h, leaf) != 0:
+        raise RenderError(_err(be))
+    return {"advance_passes": out[0], "advance_lanes": out[1], "traversal_steps": out[2], "traversal_lanes": out[3],
+            "leaf_steps": leaf[0], "leaf_lanes": leaf[1]}          # of the traversal steps: the primitive-test steps (the rest test boxes)
 
 
 def last_launch_info(b: SceneBuilder) -> dict:

@@ -258,8 +258,6 @@ def test_bvh_skip_links_thread_the_recursions_order(name, pbe, earth):
     b, _, _ = build_scene(name, pbe, earth)
     n = R.flatten(b)["bvh_nodes"]
     links = (C.c_uint32 * (4 * n))(); roots = (C.c_uint32 * 8)(); n_roots = C.c_uint32(0)
-    be.lib.rt_debug_bvh_links.restype = C.c_int
-    be.lib.rt_debug_bvh_links.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32)]
     assert be.lib.rt_debug_bvh_links(b.h, links, n, roots, 8, C.byref(n_roots)) == n
     L = np.frombuffer(links, np.uint32).reshape(n, 4)
     LEAF, DONE = 1 << 31, 0xFFFFFFFF

@@ -321,6 +321,7 @@ def test_persistent_traversal_is_scheduling_only(pbe, obe, orc_mod, seed, extra)
     _, pers = R.render(b, cam, bg, W, H, spp, depth, seed=5 + seed, flags=R.RT_PERSISTENT_BVH | extra, want_samples=True)
     tv = R.last_traversal_stats(b)
     assert tv["traversal_steps"] > 0 and 0 < tv["traversal_lanes"] <= 64 * tv["traversal_steps"]
+    assert 0 < tv["leaf_steps"] < tv["traversal_steps"] and 0 < tv["leaf_lanes"] <= 64 * tv["leaf_steps"]
     assert np.array_equal(lock.view(np.uint64), pers.view(np.uint64))
     _, auto = R.render(b, cam, bg, W, H, spp, depth, seed=5 + seed, flags=extra, want_samples=True)
     assert R.last_traversal_stats(b)["traversal_steps"] > 0          # a mesh BVH beside a list: persistent by default

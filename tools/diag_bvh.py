@@ -15,7 +15,7 @@ for key in os.environ.get('RT_WORKLOADS', 'C4').split(','):
     R.render(b, cam, bg, w.W, w.H, 32, w.max_depth, flags=flags)
     cyc = (C.c_ulonglong * 8)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
     tv = R.last_traversal_stats(b); tot = sum(cyc[:6])
-    lf = (C.c_ulonglong * 2)(); be.lib.rt_last_leaf_steps.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_last_leaf_steps(b.h, lf)
+    lf = [tv['leaf_steps'], tv['leaf_lanes']]
     nb, nl = tv['traversal_steps'] - lf[0], lf[0]
     if nl:
         print(f"{key}: box steps {nb/1e6:.1f}M at {cyc[0]/max(1,nb):.0f} wave-cycles, util {(tv['traversal_lanes']-lf[1])/max(1,64*nb):.2f} ({cyc[0]/tot*100:.1f} %); "
