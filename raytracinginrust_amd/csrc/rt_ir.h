@@ -89,7 +89,7 @@ template <typename T> struct KParams {
     const DPerlin<T>* perlins;
     const DPbr<T>* pbr;
     const uint8_t* image_bytes;
-    uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS
+    uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS: 0 in the reference's traversal order (skip links), the tree depth for near-first
     uint32_t queue_entries;        // camera paths each wave's LDS queue holds (16, 32 or 64; 80 B each)
     uint32_t n_cached;             // BVH nodes [0, n_cached) are copied into LDS by every workgroup at launch (depth order: the top levels)
     uint32_t bvh_tame;             // every BVH box is finite, below 1e300 in magnitude and has min <= max: rays that are tame too may

@@ -11,7 +11,9 @@
 //     bounce loop carrying the throughput `beta`; radiance is added when the path terminates.
 //   * top-level objects (HittableList push order) are walked with wave-uniform indices through the constant address
 //     space -> scalar loads, no VGPR cost; only (t, object, primitive) of the closest hit is kept and the hit record is
-//     rebuilt once per bounce with per-lane gathers.  BVH traversal is per-lane with its stack staged in LDS.
+//     rebuilt once per bounce with per-lane gathers.  BVH traversal is per lane and, in the reference's left-then-right order,
+//     stackless (every node carries the link to where the recursion goes next); BVH kernels run one workgroup per CU and stage
+//     the tree (or its top levels) in LDS.
 //   * per-pixel sums stay in registers (one accumulator per lane); when a lane moves to another pixel the partial sums of
 //     one pixel are combined by a masked wave butterfly and added to the frame with one hardware f64 atomic per channel.
 //   * two loop shapes: list scenes run the bounce loop in lock-step (every lane's closest-hit search costs the same); mesh scenes
@@ -435,7 +437,7 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     uint32_t sp = 0;
     const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;   // RT_NEAR_FIRST_BVH (opt-in), compile-time: no cost in the default mode
     uint32_t best_leaf = 0;
-    // "while-while" traversal with a vote: box steps (bbox test, descend / pop) and leaf steps (primitive tests) are separate, so
+    // "while-while" traversal with a vote: box steps (bbox test, next node) and leaf steps (primitive tests) are separate, so
     // that the expensive primitive tests never run with one or two lanes active.  A lane's own sequence of box tests, leaf tests
     // and t_max updates is exactly the recursion's (bbox, left, right): a lane that reaches a leaf keeps it pending and waits.
     // *Measured* against "every lane waits until all hold a leaf": final scene +8 %, random spheres +15 %; against one node (box and
@@ -1397,7 +1399,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             if (stop_below > P.trav_lo) stop_below = P.trav_lo;
             if (stop_below < 1u) stop_below = 1u;
             // Two kinds of step, chosen by vote so that each runs with many lanes: a box step (lanes that hold a node: bbox test,
-            // descend / pop; a lane that reaches a leaf keeps it pending and waits) and a leaf step (lanes with a pending leaf:
+            // next node; a lane that reaches a leaf keeps it pending and waits) and a leaf step (lanes with a pending leaf:
             // primitive tests).  Per lane the order bbox, left, right and the shrinking t_max are those of BVH::hit (bvh.rs:77-91) —
             // a lane never walks on before its pending leaf has been tested.  The box steps are an inner loop of their own with
             // nothing else in it (same shape as bvh_hit_ww's); a lane whose search ends just idles until the pass is over.
