@@ -41,7 +41,7 @@ enum {
     RT_F32 = 1,            /* throughput variant: f32 arithmetic (statistical parity only)                   */
     RT_STOP_ON_ZERO = 2,   /* opt-in: end a path whose throughput is exactly (0,0,0); differs from the
                               reference only where a later bounce would have produced NaN (0*NaN)            */
-    RT_NEAR_FIRST_BVH = 8, /* opt-in fast mode: BVH children are visited nearer-first (by the ray's sign on the split axis) instead
+    RT_NEAR_FIRST_BVH = 8, /* opt-in order (fewer node visits; faster only on some scenes): BVH children are visited nearer-first (by the ray's sign on the split axis) instead
                               of the reference's always-left-first (src/bvh.rs:81-84).  Same closest hit; exact-t ties are
                               still resolved by the reference's DFS order.  Can differ only where a last-ulp box cull depends
                               on the order hits are found.                                                                   */
