@@ -210,7 +210,7 @@ int rt_last_traversal_stats(rt_scene*, unsigned long long out4[4]);
 /* Persistent-traversal kernels: of the traversal steps above, [0] the leaf steps (primitive tests) and [1] the lanes in them. */
 int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 /* Diagnostic builds (-DRT_DIAG) only (zeros in a normal build): [0..5] wave-cycle sums of the six kernel sections, [6] rect tests
- * counted per wavefront, [7] those among them in which no lane's plane distance lay in [t_min, closest]. */
+ * counted per wavefront, [7] those among them in which no lane's plane distance lay in [t_min, closest] (-DRT_DIAG_RECTS builds). */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
 /* Test aid (host only, no GPU): the flattened BVH's link words, out[4*i..] = node i's {a, b, c, skip}: `a` bit 31 marks a leaf (then kind
  * and first primitive; b = count, c = the leaf's rank in the reference's depth-first order), otherwise a = split axis, b = right child,

@@ -314,7 +314,8 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
             const DRect<T> nxt = ld_rect(P.rects + i + 1);
             __builtin_amdgcn_sched_barrier(0);
             T t;
-#ifdef RT_DIAG      // how often a rect test could be skipped for the whole wave by a filter on t: stats[14] tests, [15] with no lane in range
+#ifdef RT_DIAG_RECTS    // (its own build: the two atomics per test distort RT_DIAG's timings) how often a rect test could be skipped for the whole
+                        // wave by a filter on t: stats[14] tests, [15] with no lane in range
             if (P.stats) {
                 const T tk = cur.plane == 2u ? (cur.k - ray.o.x) / ray.d.x : (cur.plane == 1u ? (cur.k - ray.o.y) / ray.d.y : (cur.k - ray.o.z) / ray.d.z);
                 const bool in_range = !(tk < t_min || tk > closest);

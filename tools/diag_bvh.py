@@ -12,7 +12,7 @@ flags = int(os.environ.get('RT_FLAGS', '0'))
 for key in os.environ.get('RT_WORKLOADS', 'C4').split(','):
     w = workloads.WORKLOADS[key]
     b, cam, bg = workloads.build(w, be, earth)
-    R.render(b, cam, bg, w.W, w.H, 32, w.max_depth, flags=flags)
+    R.render(b, cam, bg, w.W, w.H, int(sys.argv[1]) if len(sys.argv) > 1 else 32, w.max_depth, flags=flags)
     cyc = (C.c_ulonglong * 8)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
     tv = R.last_traversal_stats(b); tot = sum(cyc[:6])
     lf = [tv['leaf_steps'], tv['leaf_lanes']]
