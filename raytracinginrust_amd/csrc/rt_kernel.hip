@@ -476,10 +476,8 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
             if (want_box) box_step();
             // further box steps under the same vote (the vote is ~30 scalar instructions and two ballots: *measured* with two steps
             // per vote random spheres +8 %, final scene +4 %); a lane that reached a leaf or the end sits them out
-            if (!near_first) {
 #pragma unroll
-                for (int k = 1; k < RT_BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
-            }
+            for (int k = 1; k < RT_BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
         }
         if (have_leaf) {
             T t; uint32_t prim;
@@ -1434,13 +1432,11 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                         }
                     };
                     if (want_box) box_step();
-                    if (!near_first) {                                            // more box steps under the same vote (bvh_hit_ww)
 #pragma unroll
-                        for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {
-                            const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
-                            n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
-                            if (more) box_step();
-                        }
+                    for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote (bvh_hit_ww)
+                        const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
+                        n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
+                        if (more) box_step();
                     }
                 }
                 if (few) break;                                   // (pending leaves wait for the next traversal pass)
