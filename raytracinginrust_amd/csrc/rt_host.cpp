@@ -535,7 +535,6 @@ int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const
     W.P = Pn;
     auto bind = [&](int cur) { W.in = pools[cur]; W.out = pools[cur ^ 1]; };
     // LDS of the trace kernel: the top of the BVH beside the waves' stacks (no camera-path queues here)
-    P.stack_depth = f.bvh_depth;                   // (this backend's trace kernel walks with the explicit stack in either order)
     const size_t waves = shape.threads / 64u, stacks = waves * (size_t)P.stack_depth * 256u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor; if (lds_total < 65536u) lds_total = 65536u;
     size_t room = lds_total > stacks ? (lds_total - stacks) / sizeof(DBvhNode<T>) : 0;

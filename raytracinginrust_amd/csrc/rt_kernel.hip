@@ -1761,22 +1761,24 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
             uint32_t stop_below = P.trav_lo < n_bvh ? P.trav_lo : n_bvh;
             if (!work_left && n_adv == 0u) stop_below = 1u;         // nothing to hand over any more: run the stragglers out
             if (stop_below < 1u) stop_below = 1u;
+            // (the step loop of trace_resumable: box steps in an inner loop of their own, RT_BOX_STEPS_PERSIST per vote; the reference's
+            // order walks along the skip links, the nearer-first order keeps the LDS stack)
+            const bool act = phase == PH_BVH;
             for (;;) {
-                const bool act = phase == PH_BVH;
-                const uint32_t n = (uint32_t)__popcll(__ballot(act));
-                if (n < stop_below) break;
-                const bool want_leaf = act && tv_have_leaf;
-                const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
-                const uint32_t n_leaf = (uint32_t)__popcll(__ballot(want_leaf));
-                const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box));
-                n_steps++;
-                if (want_box || want_leaf) n_step_lanes++;
-                if (n_box != 0u && n_leaf * 64u < P.trav_leaf * n) {
-                    if (want_box) {
+                bool few = false;
+                for (;;) {
+                    const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
+                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(act && tv_have_leaf));
+                    few = n_box + n_leaf < stop_below;
+                    if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
+                    auto box_step = [&]() {
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, tv_closest) : box_inside_exact(nd, ray.o, inv, t_min, tv_closest);
-                        if (inside && !(nd.a & BVH_LEAF)) {
-                            const bool right_first = near_first && get(ray.d, nd.a) < T(0);
+                        if (!near_first) {
+                            if (inside && (nd.a & BVH_LEAF)) tv_have_leaf = true;             // the leaf stays the lane's node until it has been tested
+                            else tv_node = inside ? nd.c : nd.skip;
+                        } else if (inside && !(nd.a & BVH_LEAF)) {
+                            const bool right_first = get(ray.d, nd.a) < T(0);
                             stack[tv_sp * 64u] = right_first ? nd.c : nd.b;
                             tv_sp++;
                             tv_node = right_first ? nd.b : nd.c;
@@ -1785,24 +1787,37 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
                             if (tv_sp == 0u) tv_node = BVH_DONE;
                             else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
                         }
-                    }
-                } else if (n_leaf != 0u) {
-                    if (want_leaf) {
-                        T t; uint32_t prim;
-                        if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, ray, t_min, tv_closest, t, prim) &&
-                            bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
-                        tv_have_leaf = false;
+                    };
+                    n_steps++; n_step_lanes += n_box;
+                    if (want_box) box_step();
+#pragma unroll
+                    for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {
+                        const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
+                        n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
+                        if (more) box_step();
                     }
                 }
-                if (act && !tv_have_leaf && tv_node == BVH_DONE) {
-                    if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
-                    my_oi++;
-                    phase = PH_OBJ;
-                    if (my_oi < P.n_objects) {             // more objects follow: the world-space ray again (the time never changed)
-                        const WfPath<T>* src = W.in + slot;
-                        ray.o = mk<T>(src->o[0], src->o[1], src->o[2]);
-                        ray.d = mk<T>(src->d[0], src->d[1], src->d[2]);
-                    }
+                if (few) break;
+                n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(act && tv_have_leaf));
+                if (act && tv_have_leaf) {
+                    T t; uint32_t prim;
+                    if (!near_first) {
+                        const DBvhNode<T> lf = fetch_node(P, tv_node);
+                        if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; }
+                        tv_node = lf.skip;
+                    } else if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, ray, t_min, tv_closest, t, prim) &&
+                        bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
+                    tv_have_leaf = false;
+                }
+            }
+            if (act && !tv_have_leaf && tv_node == BVH_DONE) {
+                if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
+                my_oi++;
+                phase = PH_OBJ;
+                if (my_oi < P.n_objects) {             // more objects follow: the world-space ray again (the time never changed)
+                    const WfPath<T>* src = W.in + slot;
+                    ray.o = mk<T>(src->o[0], src->o[1], src->o[2]);
+                    ray.d = mk<T>(src->d[0], src->d[1], src->d[2]);
                 }
             }
             DIAG_ADD(0);
@@ -1868,9 +1883,7 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     }
     if (P.stats) {
         unsigned long long* const st = stats_row(P.stats);
-        unsigned long long b = n_step_lanes;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) b += __shfl_xor(b, off, 64);
+        const unsigned long long b = n_step_lanes;
         if (lane == 0) { atomicAdd(&st[1], n_iters); atomicAdd(&st[2], n_active); atomicAdd(&st[9], n_steps); atomicAdd(&st[10], b); }
 #ifdef RT_DIAG
         if (lane == 0) for (int q = 0; q < 2; q++) atomicAdd(&st[3 + q], dg_sum[q]);
