@@ -625,6 +625,14 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         LaunchShape wide = shape; wide.queue_entries = q;
         if (cached_nodes<T>(wide, f, prop, P.stack_depth) == P.n_cached) { shape = wide; break; }
     }
+    // a tree that does not fit anyway: 32 entries when that costs the node cache less than a fifth of its nodes — a 16-entry queue runs
+    // the camera code four times as often at a quarter of the lanes (5 % of a final-scene frame), and the deepest cached levels are
+    // worth less (*measured* final scene, 2240 nodes + 16 entries 44.6 ms, 1920 + 32 42.7 ms, 1280 + 64 46.5 ms per 64 spp)
+    if (shape.queue_entries < 32u && P.n_cached < (uint32_t)f.bvh.size()) {
+        LaunchShape wide = shape; wide.queue_entries = 32u;
+        const uint32_t n32 = cached_nodes<T>(wide, f, prop, P.stack_depth);
+        if ((uint64_t)n32 * 5u >= (uint64_t)P.n_cached * 4u) { shape = wide; P.n_cached = n32; }
+    }
     if (const char* v = std::getenv("RT_QUEUE_ENTRIES")) {       // A/B runs only: the queue first, the node cache gets what is left
         const long n = std::strtol(v, nullptr, 10);
         if (n == 16 || n == 32 || n == 64) { shape.queue_entries = (uint32_t)n; P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth); }
