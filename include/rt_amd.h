@@ -54,7 +54,8 @@ enum {
     RT_WAVEFRONT = 128,    /* scheduling only, same samples, BVH scenes only (ignored for list scenes): the frame's paths go through a
                               pool in HBM in rounds of three kernels — new camera paths / world.hit with lanes that fetch the next
                               path as soon as their search ends / hit record + material — instead of one persistent kernel.
-                              rt_render_device is synchronous with it.                                                        */
+                              rt_render_device is synchronous with it; its path pools take up to 4 GB (never more than a quarter of
+                              the device's free memory) and are released when the scene is edited or destroyed.               */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
                               old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };
@@ -168,11 +169,24 @@ int rt_render_device(rt_scene*, const rt_camera*, const double background[3], ui
  * is replicated on each selected device; tiles of tile_px output-order pixels (0 = the default, 67) are dealt round-robin, each
  * device renders its share with one persistent launch, ONE ncclGather (RCCL over xGMI; communicators from ncclCommInitAll, cached
  * with the scene; librccl is loaded on first use) brings the packed tiles to the first selected device, which un-permutes them on the
- * device; rgb_sum_out receives W*H*3 doubles in output order, as from rt_render.  Synchronous.  rt_last_multi_ms: [0] slowest
- * device's kernel, [1] gather (including the wait for the slowest device), [2] un-permute, [3] whole call, in ms. */
+ * device; rgb_sum_out receives W*H*3 doubles in output order, as from rt_render.  Synchronous.  A failure on any device leaves
+ * nothing in flight, keeps no temporary and restores the caller's current HIP device.  RT_WAVEFRONT is refused with more than one
+ * device.  rt_last_multi_ms (waits for the frame): [0] slowest device's kernel, [1] the gather as the first device's stream sees it
+ * (from the end of its own kernel: the collective including the wait for the slowest other device), [2] un-permute, [3] host clock
+ * from the call's entry to the end of the wait (rt_render_multi: of the whole call, transfer included), in ms. */
 int rt_render_multi(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
                     uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
                     uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out);
+/* The same frame left in device memory: returns once every device's work is enqueued (kernels, gather, un-permute); *d_frame_out (may
+ * be NULL) receives a DEVICE pointer on the first selected device to W*H*3 doubles in output order, owned by the scene and valid
+ * until the next rt_render_multi* call on it.  One frame is in flight per scene: the next call first waits for the previous one.
+ * rt_multi_sync waits for the frame; rt_multi_copy_frame waits and copies its first n_doubles doubles to host memory.
+ * rt_render_multi = rt_render_multi_device + rt_multi_copy_frame. */
+int rt_render_multi_device(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
+                           uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
+                           uint32_t device_mask, uint32_t tile_px, void** d_frame_out);
+int rt_multi_sync(rt_scene*);
+int rt_multi_copy_frame(rt_scene*, double* rgb_sum_out, size_t n_doubles);
 int rt_last_multi_ms(rt_scene*, double out4[4]);
 /* How BVH objects are built when the scene is flattened (at the first render / rt_scene_prepare after a change).
  * RT_BVH_MEDIAN (default) is BVH::new, src/bvh.rs:18-73: widest axis, object median.  RT_BVH_SAH is an opt-in fast mode

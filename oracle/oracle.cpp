@@ -51,7 +51,26 @@
 #include <chrono>
 #include "orc_rng.h"
 
+// -DORC_COUNT_OPS (liboracle_opcount.so only): `double` names a counting stand-in from here on, so that every f64 operation of the
+// restatement is tallied by kind (oracle/orc_opcount.h); the arithmetic and the samples are unchanged.
+#ifdef ORC_COUNT_OPS
+#include "orc_opcount.h"
+#define double orc_ops::Counted
+#endif
+
 namespace orc {
+
+// f64 operations by kind, summed over the worker threads of the renders since the last orc_op_counts() (zeros unless ORC_COUNT_OPS)
+static const int N_OP_KINDS = 18;
+static std::atomic<uint64_t> g_op_counts[N_OP_KINDS];
+#ifdef ORC_COUNT_OPS
+static_assert(N_OP_KINDS == (int)orc_ops::N_KINDS, "op kinds");
+static inline void ops_begin() { orc_ops::tl = orc_ops::Tally{}; }
+static inline void ops_end() { for (int k = 0; k < N_OP_KINDS; k++) g_op_counts[k].fetch_add(orc_ops::tl.n[k]); orc_ops::tl = orc_ops::Tally{}; }
+#else
+static inline void ops_begin() {}
+static inline void ops_end() {}
+#endif
 
 static const double PI = 3.14159265358979323846264338327950288;  // std::f64::consts::PI
 static const double F64_MAX = std::numeric_limits<double>::max();
@@ -77,8 +96,24 @@ struct Counters {
 };
 
 // thread_rng() stand-in + counters, threaded through every call that draws in the reference.
+#ifdef ORC_COUNT_OPS
+// the draws of orc_rng.h work on plain f64; their arithmetic is tallied here: u01 = one conversion and one multiply,
+// range = (v12 - 1) * (b - a) + a and the `res < b` compare (rand 0.8.5 UniformFloat::sample_single)
+struct CountingRng : Rng {
+    CountingRng() = default;
+    CountingRng(const Rng& r) : Rng(r) {}
+    double u01() { orc_ops::tick(orc_ops::CVT); orc_ops::tick(orc_ops::MUL); return double(Rng::u01()); }
+    double range(double a, double b) {
+        orc_ops::tl.n[orc_ops::ADD] += 3; orc_ops::tick(orc_ops::MUL); orc_ops::tick(orc_ops::CMP);
+        return double(Rng::range(a.v, b.v));
+    }
+};
+typedef CountingRng SamplerRng;
+#else
+typedef Rng SamplerRng;
+#endif
 struct Sampler {
-    Rng rng;
+    SamplerRng rng;
     Counters c;
 };
 
@@ -1214,9 +1249,10 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
     if (mode == 0) {
         std::atomic<uint32_t> next(row0);
         auto work = [&](int tid) {
+            ops_begin();
             for (;;) {
                 uint32_t row = next.fetch_add(1);
-                if (row >= row1) break;
+                if (row >= row1) { ops_end(); break; }
                 uint32_t j = H - 1 - row;
                 for (uint32_t i = 0; i < W; i++) {
                     Color pixel(0.0, 0.0, 0.0);
@@ -1253,9 +1289,10 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
         };
         auto worker = [&](int tid) {
             uint64_t seen = 0;
+            ops_begin();
             for (;;) {
                 while (gen.load(std::memory_order_acquire) == seen) {
-                    if (quit.load(std::memory_order_acquire)) return;
+                    if (quit.load(std::memory_order_acquire)) { ops_end(); return; }
                     std::this_thread::yield();
                 }
                 seen++;
@@ -1265,6 +1302,7 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
         };
         std::vector<std::thread> th;
         for (int t = 1; t < nthreads; t++) th.emplace_back(worker, t);
+        ops_begin();
         for (uint32_t row = row0; row < row1; row++) {
             for (uint32_t i = 0; i < W; i++) {
                 cur_i = i; cur_j = H - 1 - row;
@@ -1281,6 +1319,7 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
                 for (int ch = 0; ch < 3; ch++) out_sum[p * 3 + (size_t)ch] = pixel[ch];
             }
         }
+        ops_end();
         quit.store(true, std::memory_order_release);
         for (auto& t : th) t.join();
     }
@@ -1292,6 +1331,16 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
     return 0;
 }
 int orc_counters_n() { return Counters::N; }
+// f64 operations executed by the renders since the last call, by kind (oracle/orc_opcount.h Kind order: add/sub, mul, div, sqrt,
+// compare, min/max, sin, cos, tan, atan, atan2, acos, log, log2, pow, floor, neg/abs, int<->f64 conversions); reset on read.
+// All zero unless this library is the -DORC_COUNT_OPS build.
+int orc_op_kinds() { return N_OP_KINDS; }
+#ifdef ORC_COUNT_OPS
+int orc_counts_ops() { return 1; }
+#else
+int orc_counts_ops() { return 0; }
+#endif
+void orc_op_counts(uint64_t* out) { for (int k = 0; k < N_OP_KINDS; k++) out[k] = g_op_counts[k].exchange(0); }
 int orc_hardware_threads() { return (int)std::thread::hardware_concurrency(); }
 
 // Vec3::format_color (vec.rs:125-131) on a per-pixel sum

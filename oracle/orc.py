@@ -50,6 +50,31 @@ def load_nocount() -> Backend:
     return _nocount
 
 
+OPCOUNT_LIB_PATH = os.path.join(_HERE, "_build", "liboracle_opcount.so")
+OP_KINDS = ("add", "mul", "div", "sqrt", "cmp", "minmax", "sin", "cos", "tan", "atan", "atan2", "acos", "log", "log2", "pow", "floor",
+            "negabs", "cvt")
+_opcount = None
+
+
+def load_opcount() -> Backend:
+    """The oracle built with `double` replaced by a counting stand-in (oracle/orc_opcount.h, -DORC_COUNT_OPS): same samples, and every
+    f64 operation tallied by kind — `op_counts` reads the tallies."""
+    global _opcount
+    if _opcount is None:
+        if not os.path.exists(OPCOUNT_LIB_PATH):
+            build()
+        _opcount = _declare(C.CDLL(OPCOUNT_LIB_PATH))
+        assert _opcount.lib.orc_counts_ops() == 1 and _opcount.lib.orc_op_kinds() == len(OP_KINDS)
+    return _opcount
+
+
+def op_counts(be: Backend) -> dict:
+    """f64 operations by kind executed by the renders of `be`'s library since the last call (reset on read)."""
+    n = np.zeros(len(OP_KINDS), dtype=np.uint64)
+    be.lib.orc_op_counts(C.c_void_p(n.ctypes.data))
+    return dict(zip(OP_KINDS, [int(x) for x in n]))
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", _HERE])
 

@@ -1,12 +1,13 @@
-"""Identity of the kernel sources in this tree: profiles/ snapshots carry it, and bench.py only quotes counters from a profile
-that was taken on the same kernels."""
+"""Identity of the kernel sources AND of the launch code in this tree (the launch shape — queue entries, LDS node cache, chunk size,
+workgroups per CU — lives in rt_host.cpp and drives the PMC counters as much as the kernels do): profiles/ snapshots carry it, and
+bench.py only quotes counters from a profile that was taken on the same build."""
 from __future__ import annotations
 
 import hashlib
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-KERNEL_SOURCES = ("rt_kernel.hip", "rt_ir.h", "rt_rng.h", "rt_launch.h", "Makefile")
+KERNEL_SOURCES = ("rt_kernel.hip", "rt_ir.h", "rt_rng.h", "rt_launch.h", "rt_host.cpp", "rt_scene.h", "Makefile")
 
 
 def kernel_source_id() -> str:

@@ -85,7 +85,10 @@ static void touch(rt_scene* sc) {
     sc->s.invalidate();
     if (sc->s.ctxs.empty()) return;
     int cur = 0; (void)hipGetDevice(&cur);
-    for (Scene::DeviceCtx* c : sc->s.ctxs) { (void)hipSetDevice(c->device); free_device_scene(c->dev64); free_device_scene(c->dev32); }
+    for (Scene::DeviceCtx* c : sc->s.ctxs) {
+        (void)hipSetDevice(c->device); free_device_scene(c->dev64); free_device_scene(c->dev32);
+        if (c->d_wf) { (void)hipFree(c->d_wf); c->d_wf = nullptr; c->wf_bytes = 0; }     // the wavefront backend's path pools (GBs) do not outlive a scene edit
+    }
     (void)hipSetDevice(cur);
 }
 int rt_scene_set_traversal_schedule(rt_scene* sc, uint32_t start_at, uint32_t stop_below, uint32_t leaf_share64) {
@@ -518,10 +521,17 @@ int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const
     }
     (void)n_local_px;
     const uint64_t total = n_real * P.spp;
-    uint64_t pool = 16ull << 20;                   // paths in flight (2 GB of records per pool in f64); *measured* 16 M beats 4 M by 7-15 %
+    uint64_t pool = 16ull << 20;                   // paths in flight: two pools of 128-byte records = 4 GB in f64; *measured* 16 M beats 4 M by 7-15 %
     if (const char* v = std::getenv("RT_WF_POOL")) { const long long n = std::strtoll(v, nullptr, 10); if (n >= 64 && n <= (1ll << 26)) pool = (uint64_t)n; }
     if (pool > total) pool = total;
-    if (pool == 0) return 0;
+    {   // never more than a quarter of what the device has free (beside what this context already holds for the pools)
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
+            const uint64_t cap = ((uint64_t)mem_free + c.wf_bytes) / 4u / (2u * sizeof(WfPath<T>));
+            if (pool > cap) pool = cap;
+        }
+    }
+    if (pool == 0) return set_err("wavefront backend: no device memory for the path pools");
     const uint32_t Pn = (uint32_t)pool;
     // one allocation: the two pools (one aligned record per path) and the counters
     const size_t need = 2 * (size_t)Pn * sizeof(WfPath<T>) + 256;
@@ -720,12 +730,19 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     if (!sc) return set_err("null argument");
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
-    Scene& s = sc->s;
     Scene::DeviceCtx* cp = nullptr;
-    if (current_ctx(s, &cp)) return -1;
-    if (flags & RT_F32) { if (ensure_uploaded<float>(s, cp->dev32)) return -1; }
-    else { if (ensure_uploaded<double>(s, cp->dev64)) return -1; }
-    for (Scene::LaunchSlot& l : cp->slots) {
+    if (current_ctx(sc->s, &cp)) return -1;
+    return rt::prepare_device(sc->s, *cp, flags);
+}
+
+} // extern "C"
+namespace rt {
+// rt_scene_prepare's work for one device context; the calling thread's current HIP device must be c.device and the scene must be
+// flattened.  Touches only `c` and reads s.flat, so rt_render_multi may run it for several devices from several threads at once.
+int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
+    if (flags & RT_F32) { if (ensure_uploaded<float>(s, c.dev32)) return -1; }
+    else { if (ensure_uploaded<double>(s, c.dev64)) return -1; }
+    for (Scene::LaunchSlot& l : c.slots) {
         if (!l.d_queue) HIP_OK(hipMalloc(&l.d_queue, 64));
         if (!l.d_stats) HIP_OK(hipMalloc(&l.d_stats, RT_STATS_BYTES));
         if (!l.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_start = e; }
@@ -733,7 +750,7 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     }
     const uint32_t eff = effective_flags(s.flat, flags);
     const LaunchShape shape = pathtrace_shape(s.flat.feats, eff);
-    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, cp->device));
+    hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     int bpc;
     const uint32_t sd = stack_depth_of(s.flat, eff);
     if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), sizeof(DBvhNode<float>)));
@@ -742,9 +759,7 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
     HIP_OK(hipDeviceSynchronize());
     return 0;
 }
-
-} // extern "C"
-namespace rt {
+bool flatten_for_render(Scene& s) { if (flatten_scene(s)) return true; set_err(s.error); return false; }
 int device_kernel_ms(Scene& s, int device, float* ms) {
     for (Scene::DeviceCtx* c : s.ctxs) if (c->device == device && c->last_slot >= 0) {
         Scene::LaunchSlot& l = c->slots[c->last_slot];

@@ -12,6 +12,10 @@
 //     the caller's host buffer in one transfer.
 // RCCL is loaded with dlopen on first use (librccl.so.1 — the copy already in the process when the host is PyTorch), so that
 // librt_amd.so carries no link-time dependency on it and single-GPU users never load it.
+//
+// Entry points: rt_render_multi_device enqueues the frame on every device and returns (the frame stays on the root device),
+// rt_multi_sync waits for it and settles the timings, rt_multi_copy_frame fetches it; rt_render_multi = all three.  Every failure
+// leaves through one tail that waits for what was already launched, keeps no temporary alive and restores the caller's HIP device.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <unistd.h>
@@ -20,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include "../../include/rt_amd.h"
 #include "rt_scene.h"
@@ -28,7 +33,6 @@ using namespace rt;
 
 namespace rt {
 int set_error(const std::string& m);          // rt_host.cpp: rt_last_error()'s message; returns -1
-int device_kernel_ms(Scene& s, int device, float* ms);
 }
 
 namespace {
@@ -68,9 +72,6 @@ Rccl* rccl() {
     return &r;
 }
 
-#define HIPX(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return set_error(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
-#define NCCLX(call) do { int r_ = (call); if (r_ != 0) return set_error(std::string(#call) + ": " + R->GetErrorString(r_)); } while (0)
-
 // gathered[rank][q][k][3] (tile t = rank + q * world, pixel k of the tile) -> frame[p][3], p = t * tile_px + k: one thread per
 // output double, consecutive threads write consecutive addresses and read runs of tile_px * 3 consecutive ones (HBM-bound copy).
 __global__ void unpermute_tiles(const double* __restrict__ gathered, double* __restrict__ frame, unsigned long long n_px,
@@ -83,58 +84,144 @@ __global__ void unpermute_tiles(const double* __restrict__ gathered, double* __r
     frame[i] = gathered[((rank * n_local_tiles + q) * tile_px + k) * 3ull + c];
 }
 
-int ensure_buffer(void*& p, size_t& have, size_t need) {
-    if (have >= need) return 0;
+std::string hip_msg(const char* what, hipError_t e) { return std::string(what) + ": " + hipGetErrorString(e); }
+
+bool ensure_buffer(void*& p, size_t& have, size_t need, std::string& err) {
+    if (have >= need) return true;
     if (p) { (void)hipFree(p); p = nullptr; have = 0; }
-    HIPX(hipMalloc(&p, need));
+    const hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) { p = nullptr; err = hip_msg("hipMalloc", e); return false; }
     have = need;
-    return 0;
+    return true;
+}
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// Wait for everything the frame in flight put on the devices' streams (also the way out of a failed call: nothing of it may still
+// be running when its buffers are reused or freed).  Leaves the current device at the last one visited.
+void drain(Scene& s) {
+    for (int d : s.multi_devs) {
+        for (Scene::DeviceCtx* c : s.ctxs) if (c->device == d && c->stream) { (void)hipSetDevice(d); (void)hipStreamSynchronize((hipStream_t)c->stream); }
+    }
 }
 
 } // namespace
 
 namespace rt {
 void multi_release(Scene& s) {
+    if (s.multi_pending) { int cur = 0; (void)hipGetDevice(&cur); drain(s); (void)hipSetDevice(cur); s.multi_pending = false; }
+    if (s.multi_ev_device >= 0) {
+        int cur = 0; (void)hipGetDevice(&cur);
+        (void)hipSetDevice(s.multi_ev_device);
+        for (void*& e : s.multi_ev) if (e) { (void)hipEventDestroy((hipEvent_t)e); e = nullptr; }
+        s.multi_ev_device = -1;
+        (void)hipSetDevice(cur);
+    }
+    if (!s.virtual_tiles.empty()) {
+        int cur = 0; (void)hipGetDevice(&cur);
+        (void)hipSetDevice(s.virtual_tiles_device);
+        for (void* p : s.virtual_tiles) if (p) (void)hipFree(p);
+        s.virtual_tiles.clear(); s.virtual_tiles_bytes = 0; s.virtual_tiles_device = -1;
+        (void)hipSetDevice(cur);
+    }
+    if (s.comms.empty()) return;                 // single-GPU users never touch (or load) RCCL, not even at teardown
     Rccl* R = rccl();
     if (R->lib) for (void* c : s.comms) if (c) (void)R->CommDestroy(c);
     s.comms.clear(); s.comm_devices.clear();
 }
 }
 
-extern "C" {
+namespace {
 
-int rt_render_multi(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
-                    uint64_t seed, uint32_t flags, uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out) {
-    if (!sc || !cam || !bg || !rgb_sum_out) return set_error("null argument");
-    const auto t_call = std::chrono::steady_clock::now();
+// The frame on N devices, enqueued: everything up to and including the un-permute on the root device's stream.  On failure the
+// message is in `err` and the caller runs the cleanup tail.
+bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                   uint64_t seed, uint32_t flags, uint32_t device_mask, uint32_t tile_px, std::string& err) {
+    Scene& s = sc->s;
     const int n_visible = rt_device_count();
-    if (n_visible <= 0) return set_error("no HIP device: librt_amd has no CPU rendering path");
+    if (n_visible <= 0) { err = "no HIP device: librt_amd has no CPU rendering path"; return false; }
     std::vector<int> devs;
     for (int d = 0; d < n_visible && d < 32; d++) if (device_mask == 0u || (device_mask >> d) & 1u) devs.push_back(d);
-    if (devs.empty() || (device_mask != 0u && n_visible < 32 && (device_mask >> n_visible) != 0u))
-        return set_error("device_mask selects a device that is not visible (rt_device_count() = " + std::to_string(n_visible) + ")");
-    if (tile_px == 0) tile_px = 67;                 // the default of dist.py: a prime, so that tile columns drift across rows
-    // Test hook (tests/test_multi_gpu.py): RT_MULTI_VIRTUAL_RANKS=N deals the tiles to N ranks that all live on the FIRST selected
-    // device, one after the other, and "gathers" with device-to-device copies — the tile arithmetic and the un-permute kernel of an
-    // N-GPU frame on a one-GPU box.  Never set in production.
+    if (devs.empty() || (device_mask != 0u && n_visible < 32 && (device_mask >> n_visible) != 0u)) {
+        err = "device_mask selects a device that is not visible (rt_device_count() = " + std::to_string(n_visible) + ")"; return false;
+    }
+    // Test hooks (tests/test_multi_gpu.py), never set in production.  RT_MULTI_VIRTUAL_RANKS=N deals the tiles to N ranks that all
+    // live on the FIRST selected device, one after the other, and "gathers" with device-to-device copies — the tile arithmetic and the
+    // un-permute kernel of an N-GPU frame on a one-GPU box.  RT_MULTI_FAIL_RANK=r makes rank r's launch fail after the ranks before
+    // it were launched — the error path of an N-GPU frame.
     uint32_t virtual_ranks = 0;
     if (const char* v = std::getenv("RT_MULTI_VIRTUAL_RANKS")) { long n = std::strtol(v, nullptr, 10); if (n >= 1 && n <= 64) virtual_ranks = (uint32_t)n; }
+    long fail_rank = -1;
+    if (const char* v = std::getenv("RT_MULTI_FAIL_RANK")) fail_rank = std::strtol(v, nullptr, 10);
     if (virtual_ranks) devs.assign(virtual_ranks, devs[0]);
     const uint32_t N = (uint32_t)devs.size();
-    Scene& s = sc->s;
-    int cur = 0; HIPX(hipGetDevice(&cur));
+    if ((flags & RT_WAVEFRONT) && N > 1) { err = "RT_WAVEFRONT is a synchronous single-device measurement backend: not available in rt_render_multi with more than one rank"; return false; }
+    if (!rt::flatten_for_render(s)) { err = rt_last_error(); return false; }
+    if (W < 2 || H < 2 || spp == 0 || (uint64_t)W * H > 0x7FFFFFFFull) {      // rt_render_device repeats these with its own messages
+        err = "bad frame: W and H must be >= 2, samples_per_pixel >= 1, W*H <= 2^31 - 1"; return false;
+    }
     const uint32_t n_local = rt_local_tiles(W, H, tile_px, 0, N);
     const size_t tiles_bytes = (size_t)n_local * tile_px * 3 * sizeof(double);
     const unsigned long long n_px = (unsigned long long)W * H;
     // RT_MULTI_COLLECTIVE: force the collective path on one device too (lets a 1-GPU box exercise the RCCL calls)
     const bool collective = !virtual_ranks && (N > 1 || (flags & RT_MULTI_COLLECTIVE) != 0u);
-    std::vector<void*> rank_tiles(N, nullptr);      // each rank's packed tile buffer (virtual ranks: temporaries on the one device)
+    s.multi_devs.assign(devs.begin(), devs.end());
+    hipError_t e;
+
+    // ---- per-device one-time work (first use of a device: context, code object, scene upload, stream) from one thread per
+    //      device, so that an 8-GPU node does not do it eight times in a row; every thread touches its own DeviceCtx only
+    std::vector<Scene::DeviceCtx*> ctx(N, nullptr);
+    for (uint32_t r = 0; r < N; r++) ctx[r] = &s.ctx_for(devs[r]);
+    {
+        const uint32_t n_distinct = virtual_ranks ? 1u : N;
+        std::vector<std::string> perr(n_distinct);
+        auto prep = [&](uint32_t r) {
+            Scene::DeviceCtx& c = *ctx[r];
+            hipError_t pe = hipSetDevice(devs[r]);
+            if (pe != hipSuccess) { perr[r] = hip_msg("hipSetDevice", pe); return; }
+            const bool f32 = (flags & RT_F32) != 0u;
+            if (!(f32 ? c.dev32.valid : c.dev64.valid) || !c.slots[0].ev_start) {
+                if (rt::prepare_device(s, c, flags)) { perr[r] = rt_last_error(); return; }
+            }
+            if (!c.stream) { hipStream_t st; pe = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); if (pe != hipSuccess) { perr[r] = hip_msg("hipStreamCreate", pe); return; } c.stream = st; }
+            if (!virtual_ranks && !ensure_buffer(c.d_tiles, c.tiles_bytes, tiles_bytes, perr[r])) return;
+            if (r == 0) {
+                if ((collective || virtual_ranks) && !ensure_buffer(c.d_gather, c.gather_bytes, tiles_bytes * N, perr[r])) return;
+                if (!ensure_buffer(c.d_frame, c.frame_bytes, (size_t)n_px * 3 * sizeof(double), perr[r])) return;
+            }
+        };
+        if (n_distinct == 1) prep(0);
+        else {
+            std::vector<std::thread> th;
+            for (uint32_t r = 0; r < n_distinct; r++) th.emplace_back(prep, r);
+            for (std::thread& t : th) t.join();
+        }
+        for (uint32_t r = 0; r < n_distinct; r++) if (!perr[r].empty()) { err = "device " + std::to_string(devs[r]) + ": " + perr[r]; return false; }
+    }
+    Scene::DeviceCtx& root = *ctx[0];
+    if ((e = hipSetDevice(devs[0])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
+    if (s.multi_ev_device != devs[0]) {
+        if (s.multi_ev_device >= 0) { (void)hipSetDevice(s.multi_ev_device); for (void*& ev : s.multi_ev) if (ev) { (void)hipEventDestroy((hipEvent_t)ev); ev = nullptr; } (void)hipSetDevice(devs[0]); }
+        s.multi_ev_device = devs[0];
+        for (void*& ev : s.multi_ev) { hipEvent_t x; if ((e = hipEventCreate(&x)) != hipSuccess) { err = hip_msg("hipEventCreate", e); return false; } ev = x; }
+    }
+    std::vector<void*> rank_tiles(N, nullptr);      // each rank's packed tile buffer (virtual ranks: buffers on the one device, kept with the scene)
+    if (virtual_ranks) {
+        if (s.virtual_tiles.size() != N || s.virtual_tiles_bytes < tiles_bytes || s.virtual_tiles_device != devs[0]) {
+            if (!s.virtual_tiles.empty()) { (void)hipSetDevice(s.virtual_tiles_device); for (void* p : s.virtual_tiles) if (p) (void)hipFree(p); (void)hipSetDevice(devs[0]); }
+            s.virtual_tiles.assign(N, nullptr); s.virtual_tiles_bytes = tiles_bytes; s.virtual_tiles_device = devs[0];
+            for (uint32_t r = 0; r < N; r++) if ((e = hipMalloc(&s.virtual_tiles[r], tiles_bytes)) != hipSuccess) { s.virtual_tiles[r] = nullptr; err = hip_msg("hipMalloc", e); return false; }
+        }
+        rank_tiles = s.virtual_tiles;
+    } else {
+        for (uint32_t r = 0; r < N; r++) rank_tiles[r] = ctx[r]->d_tiles;
+    }
     Rccl* R = nullptr;
     if (collective) {
         R = rccl();
-        if (!R->lib) return set_error(R->err);
+        if (!R->lib) { err = R->err; return false; }
         if (s.comm_devices != devs) {
-            rt::multi_release(s);
+            if (!s.comms.empty()) { for (void* c : s.comms) if (c) (void)R->CommDestroy(c); s.comms.clear(); s.comm_devices.clear(); }
             s.comms.assign(N, nullptr);
             // RCCL prints a version banner to stdout when it initialises; the reference's contract is "the image IS stdout"
             // (`cargo run --release > image.ppm`, README.md:4), so stdout points at stderr while the communicators are created
@@ -144,76 +231,127 @@ int rt_render_multi(rt_scene* sc, const rt_camera* cam, const double bg[3], uint
             const int init_rc = R->CommInitAll(s.comms.data(), (int)N, devs.data());
             std::fflush(stdout);
             if (saved_out >= 0) { (void)dup2(saved_out, 1); (void)close(saved_out); }
-            NCCLX(init_rc);
+            if (init_rc != 0) { s.comms.clear(); err = std::string("ncclCommInitAll: ") + R->GetErrorString(init_rc); return false; }
             s.comm_devices = devs;
         }
     }
+    // ---- every device: its share of the tiles, asynchronously on its own stream (one thread: a launch is a few microseconds)
+    for (uint32_t r = 0; r < N; r++) {
+        if ((e = hipSetDevice(devs[r])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
+        if ((long)r == fail_rank) { err = "rank " + std::to_string(r) + ": injected failure (RT_MULTI_FAIL_RANK)"; return false; }
+        if (rt_render_device(sc, cam, bg, W, H, spp, max_depth, seed, flags & ~(uint32_t)RT_MULTI_COLLECTIVE, tile_px, r, N, rank_tiles[r], tiles_bytes, ctx[r]->stream)) {
+            err = "rank " + std::to_string(r) + " (device " + std::to_string(devs[r]) + "): " + rt_last_error(); return false;
+        }
+    }
+    // ---- one gather to the root device (rank 0), each rank's part ordered behind its own kernel on its own stream
+    if ((e = hipSetDevice(devs[0])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
+    const hipStream_t rs = (hipStream_t)root.stream;
+    if ((e = hipEventRecord((hipEvent_t)s.multi_ev[0], rs)) != hipSuccess) { err = hip_msg("hipEventRecord", e); return false; }   // fires when the root's own kernel is done
+    if (collective) {
+        int g = R->GroupStart();
+        if (g != 0) { err = std::string("ncclGroupStart: ") + R->GetErrorString(g); return false; }
+        for (uint32_t r = 0; r < N && g == 0; r++)
+            g = R->Gather(rank_tiles[r], r == 0 ? root.d_gather : nullptr, (size_t)n_local * tile_px * 3, NCCL_DOUBLE, 0, s.comms[r], (hipStream_t)ctx[r]->stream);
+        const int ge = R->GroupEnd();                                 // always closed, also after a failed ncclGather
+        if (g != 0) { err = std::string("ncclGather: ") + R->GetErrorString(g); return false; }
+        if (ge != 0) { err = std::string("ncclGroupEnd: ") + R->GetErrorString(ge); return false; }
+    } else if (virtual_ranks) {
+        for (uint32_t r = 0; r < N; r++)
+            if ((e = hipMemcpyAsync((char*)root.d_gather + (size_t)r * tiles_bytes, rank_tiles[r], tiles_bytes, hipMemcpyDeviceToDevice, rs)) != hipSuccess) { err = hip_msg("hipMemcpyAsync", e); return false; }
+    }
+    if ((e = hipSetDevice(devs[0])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
+    if ((e = hipEventRecord((hipEvent_t)s.multi_ev[1], rs)) != hipSuccess) { err = hip_msg("hipEventRecord", e); return false; }
+    // ---- un-permute on the root device into output order
+    const unsigned long long n_out = n_px * 3ull;
+    const unsigned block = 256; const unsigned long long grid = (n_out + block - 1) / block;
+    hipLaunchKernelGGL(unpermute_tiles, dim3((unsigned)grid), dim3(block), 0, rs,
+                       (const double*)((collective || virtual_ranks) ? root.d_gather : rank_tiles[0]), (double*)root.d_frame, n_px, tile_px, N, (unsigned long long)n_local);
+    if ((e = hipGetLastError()) != hipSuccess) { err = hip_msg("un-permute launch", e); return false; }
+    if ((e = hipEventRecord((hipEvent_t)s.multi_ev[2], rs)) != hipSuccess) { err = hip_msg("hipEventRecord", e); return false; }
+    return true;
+}
+
+// Wait for the frame in flight and settle rt_last_multi_ms.
+int settle(Scene& s) {
+    if (!s.multi_pending) return 0;
+    int cur = 0; (void)hipGetDevice(&cur);
+    drain(s);
+    s.multi_pending = false;
+    (void)hipSetDevice(s.multi_devs[0]);
+    float g_ms = 0.f, u_ms = 0.f, k_max = 0.f;
+    // both on the root's stream: [0] fires when the root's own kernel is done, [1] when the gather behind it is — the collective
+    // including the wait for the slowest other device
+    const hipError_t e1 = hipEventElapsedTime(&g_ms, (hipEvent_t)s.multi_ev[0], (hipEvent_t)s.multi_ev[1]);
+    const hipError_t e2 = hipEventElapsedTime(&u_ms, (hipEvent_t)s.multi_ev[1], (hipEvent_t)s.multi_ev[2]);
     int rc = 0;
-    // ---- every device: its share of the tiles, asynchronously on its own stream
-    for (uint32_t r = 0; r < N && rc == 0; r++) {
-        hipError_t e = hipSetDevice(devs[r]);
-        if (e != hipSuccess) { rc = set_error(std::string("hipSetDevice: ") + hipGetErrorString(e)); break; }
-        Scene::DeviceCtx& c = s.ctx_for(devs[r]);
-        if (!c.stream) { hipStream_t st; e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking); if (e != hipSuccess) { rc = set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e)); break; } c.stream = st; }
-        if (virtual_ranks) { e = hipMalloc(&rank_tiles[r], tiles_bytes); if (e != hipSuccess) { rc = set_error(std::string("hipMalloc: ") + hipGetErrorString(e)); break; } }
-        else { if (ensure_buffer(c.d_tiles, c.tiles_bytes, tiles_bytes)) { rc = -1; break; } rank_tiles[r] = c.d_tiles; }
-        if (r == 0) {
-            if ((collective || virtual_ranks) && ensure_buffer(c.d_gather, c.gather_bytes, tiles_bytes * N)) { rc = -1; break; }
-            if (ensure_buffer(c.d_frame, c.frame_bytes, (size_t)n_px * 3 * sizeof(double))) { rc = -1; break; }
-        }
-        rc = rt_render_device(sc, cam, bg, W, H, spp, max_depth, seed, flags & ~(uint32_t)RT_MULTI_COLLECTIVE, tile_px, r, N, rank_tiles[r], tiles_bytes, c.stream);
+    if (e1 != hipSuccess || e2 != hipSuccess) rc = set_error(hip_msg("rt_render_multi: a device reported an error while the frame ran", e1 != hipSuccess ? e1 : e2));
+    std::vector<int> seen;
+    for (int d : s.multi_devs) {
+        bool dup = false; for (int x : seen) dup = dup || x == d;
+        if (dup) continue;
+        seen.push_back(d);
+        float k = 0.f; if (device_kernel_ms(s, d, &k) == 0 && k > k_max) k_max = k;
     }
-    // ---- one gather to the root device (rank 0), each rank's part ordered behind its own kernel
-    Scene::DeviceCtx& root = s.ctx_for(devs[0]);
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    if (rc == 0) {
-        (void)hipSetDevice(devs[0]);
-        for (hipEvent_t& e : ev) if (hipEventCreate(&e) != hipSuccess) rc = set_error("hipEventCreate failed");
-    }
-    if (rc == 0) {
-        HIPX(hipEventRecord(ev[0], (hipStream_t)root.stream));
-        if (collective) {
-            NCCLX(R->GroupStart());
-            for (uint32_t r = 0; r < N; r++) {
-                Scene::DeviceCtx& c = s.ctx_for(devs[r]);
-                int g = R->Gather(rank_tiles[r], r == 0 ? root.d_gather : nullptr, (size_t)n_local * tile_px * 3, NCCL_DOUBLE, 0, s.comms[r], (hipStream_t)c.stream);
-                if (g != 0) { (void)R->GroupEnd(); return set_error(std::string("ncclGather: ") + R->GetErrorString(g)); }
-            }
-            NCCLX(R->GroupEnd());
-        } else if (virtual_ranks) {
-            for (uint32_t r = 0; r < N; r++)
-                HIPX(hipMemcpyAsync((char*)root.d_gather + (size_t)r * tiles_bytes, rank_tiles[r], tiles_bytes, hipMemcpyDeviceToDevice, (hipStream_t)root.stream));
-        }
-        HIPX(hipSetDevice(devs[0]));
-        HIPX(hipEventRecord(ev[1], (hipStream_t)root.stream));
-        // ---- un-permute on the root device into output order, then one transfer to the caller's buffer
-        const unsigned long long n_out = n_px * 3ull;
-        const unsigned block = 256; const unsigned long long grid = (n_out + block - 1) / block;
-        hipLaunchKernelGGL(unpermute_tiles, dim3((unsigned)grid), dim3(block), 0, (hipStream_t)root.stream,
-                           (const double*)((collective || virtual_ranks) ? root.d_gather : rank_tiles[0]), (double*)root.d_frame, n_px, tile_px, N, (unsigned long long)n_local);
-        HIPX(hipGetLastError());
-        HIPX(hipEventRecord(ev[2], (hipStream_t)root.stream));
-        HIPX(hipMemcpyAsync(rgb_sum_out, root.d_frame, (size_t)n_out * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)root.stream));
-        HIPX(hipEventRecord(ev[3], (hipStream_t)root.stream));
-        for (uint32_t r = 0; r < N; r++) { HIPX(hipSetDevice(devs[r])); HIPX(hipStreamSynchronize((hipStream_t)s.ctx_for(devs[r]).stream)); }
-        HIPX(hipSetDevice(devs[0]));
-        float g_ms = 0.f, u_ms = 0.f, k_max = 0.f;
-        (void)hipEventElapsedTime(&g_ms, ev[0], ev[1]);             // on the root's stream: its own kernel + the gather behind it
-        (void)hipEventElapsedTime(&u_ms, ev[1], ev[2]);
-        for (uint32_t r = 0; r < N; r++) { float k = 0.f; if (device_kernel_ms(s, devs[r], &k) == 0 && k > k_max) k_max = k; }
-        s.multi_ms[0] = k_max; s.multi_ms[1] = g_ms; s.multi_ms[2] = u_ms;
-        s.multi_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count();
-    }
-    for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
-    if (virtual_ranks) for (void* p : rank_tiles) if (p) (void)hipFree(p);
+    s.multi_ms[0] = k_max; s.multi_ms[1] = g_ms; s.multi_ms[2] = u_ms; s.multi_ms[3] = now_ms() - s.multi_t0;
     (void)hipSetDevice(cur);
     return rc;
 }
 
-// Timings of the last rt_render_multi (ms): [0] slowest device's path-tracing kernel, [1] root stream from launch to the end of the
-// gather (its own kernel + the collective), [2] un-permute kernel, [3] the whole call on the host clock.
+} // namespace
+
+extern "C" {
+
+int rt_render_multi_device(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                           uint64_t seed, uint32_t flags, uint32_t device_mask, uint32_t tile_px, void** d_frame_out) {
+    if (!sc || !cam || !bg) return set_error("null argument");
+    if (rt_device_count() <= 0) return set_error("no HIP device: librt_amd has no CPU rendering path");
+    Scene& s = sc->s;
+    if (settle(s)) return -1;                       // one frame in flight per scene: the buffers are the scene's
+    if (tile_px == 0) tile_px = 67;                 // the default of dist.py: a prime, so that tile columns drift across rows
+    int cur = 0;
+    { const hipError_t e = hipGetDevice(&cur); if (e != hipSuccess) return set_error(hip_msg("hipGetDevice", e)); }
+    s.multi_t0 = now_ms();
+    std::string err;
+    const bool ok = enqueue_frame(sc, cam, bg, W, H, spp, max_depth, seed, flags, device_mask, tile_px, err);
+    if (!ok) drain(s);                              // whatever was launched before the failure finishes before anything is reused
+    s.multi_pending = ok;
+    if (ok && d_frame_out) *d_frame_out = s.ctx_for(s.multi_devs[0]).d_frame;
+    (void)hipSetDevice(cur);                        // a PyTorch host keeps its current device
+    return ok ? 0 : set_error(err);
+}
+
+int rt_multi_sync(rt_scene* sc) {
+    if (!sc) return set_error("null argument");
+    return settle(sc->s);
+}
+
+int rt_multi_copy_frame(rt_scene* sc, double* rgb_sum_out, size_t n_doubles) {
+    if (!sc || !rgb_sum_out) return set_error("null argument");
+    Scene& s = sc->s;
+    if (settle(s)) return -1;
+    if (s.multi_devs.empty()) return set_error("no rt_render_multi frame has been rendered for this scene");
+    Scene::DeviceCtx& root = s.ctx_for(s.multi_devs[0]);
+    if (!root.d_frame || n_doubles * sizeof(double) > root.frame_bytes) return set_error("rt_multi_copy_frame: more doubles asked for than the last frame holds");
+    const hipError_t e = hipMemcpy(rgb_sum_out, root.d_frame, n_doubles * sizeof(double), hipMemcpyDeviceToHost);
+    return e == hipSuccess ? 0 : set_error(hip_msg("hipMemcpy(frame)", e));
+}
+
+int rt_render_multi(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                    uint64_t seed, uint32_t flags, uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out) {
+    if (!rgb_sum_out) return set_error("null argument");
+    if (rt_render_multi_device(sc, cam, bg, W, H, spp, max_depth, seed, flags, device_mask, tile_px, nullptr)) return -1;
+    const double t0 = sc->s.multi_t0;
+    if (rt_multi_copy_frame(sc, rgb_sum_out, (size_t)W * H * 3)) return -1;
+    sc->s.multi_ms[3] = now_ms() - t0;              // the whole call, transfer to the host included
+    return 0;
+}
+
+// Timings of the last rt_render_multi* frame (ms; waits for it): [0] slowest device's path-tracing kernel, [1] on the root's stream
+// from the end of its own kernel to the end of the gather (the collective, including the wait for the slowest other device),
+// [2] un-permute kernel, [3] host clock from the call's entry to the end of the wait (rt_render_multi: of the whole call).
 int rt_last_multi_ms(rt_scene* sc, double out4[4]) {
     if (!sc || !out4) return set_error("null argument");
+    if (settle(sc->s)) return -1;
     for (int k = 0; k < 4; k++) out4[k] = sc->s.multi_ms[k];
     return 0;
 }

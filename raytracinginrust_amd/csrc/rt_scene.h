@@ -89,7 +89,12 @@ struct Scene {
     uint32_t launch_info[6] = {0, 0, 0, 0, 0, 0};      // rt_last_launch_info
     // rt_render_multi: RCCL communicators of the last device set (csrc/rt_multi.cpp)
     std::vector<int> comm_devices; std::vector<void*> comms;
-    double multi_ms[4] = {0, 0, 0, 0};     // last rt_render_multi: slowest device's kernel, gather, un-permute, whole call (wall)
+    double multi_ms[4] = {0, 0, 0, 0};     // last rt_render_multi*: slowest device's kernel, gather, un-permute, whole call (wall)
+    // state of the rt_render_multi* frame in flight (rt_multi_sync settles it): the devices it runs on, four events on the root
+    // device's stream, the host clock at the call's entry; the virtual-rank test hook's tile buffers (all on the root device)
+    std::vector<int> multi_devs; bool multi_pending = false; double multi_t0 = 0.0;
+    void* multi_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int multi_ev_device = -1;
+    std::vector<void*> virtual_tiles; size_t virtual_tiles_bytes = 0; int virtual_tiles_device = -1;
     double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
 
     void invalidate() { flat_valid = false; }
@@ -105,6 +110,8 @@ bool flatten_scene(Scene& s);
 // rt_host.cpp (shared with rt_multi.cpp)
 int set_error(const std::string& m);                              // leaves the message for rt_last_error(); returns -1
 int device_kernel_ms(Scene& s, int device, float* ms);            // duration of the last path-tracing kernel launched on `device`
+int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags); // rt_scene_prepare's work for one device (current device = c.device)
+bool flatten_for_render(Scene& s);                                // flatten_scene + rt_last_error on failure
 void multi_release(Scene& s);                                     // rt_multi.cpp: destroys the cached RCCL communicators
 // camera (src/camera.rs:19-49)
 struct rt_camera_args { double lookfrom[3], lookat[3], vup[3], vfov, aspect, aperture, focus_dist, time0, time1; };

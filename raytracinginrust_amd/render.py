@@ -97,6 +97,33 @@ def render_multi(b: SceneBuilder, cam: CameraParams, background, W: int, H: int,
     return out
 
 
+def render_multi_device(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int, device_mask: int = 0,
+                        seed: int = 0x5EED, flags: int = RT_F64, tile_px: int = 0) -> int:
+    """rt_render_multi_device: enqueue the frame on the selected devices and return the DEVICE address (first selected device) of
+    its W*H*3 per-pixel sums; `multi_sync` waits for it, `multi_frame` fetches it."""
+    be = _lib.load()
+    bg = (C.c_double * 3)(*[float(x) for x in background])
+    ptr = C.c_void_p()
+    if be.lib.rt_render_multi_device(b.h, C.byref(cam), bg, W, H, spp, max_depth, seed, flags, device_mask, tile_px, C.byref(ptr)) != 0:
+        raise RenderError(_err(be))
+    return int(ptr.value or 0)
+
+
+def multi_sync(b: SceneBuilder) -> None:
+    be = _lib.load()
+    if be.lib.rt_multi_sync(b.h) != 0:
+        raise RenderError(_err(be))
+
+
+def multi_frame(b: SceneBuilder, W: int, H: int) -> np.ndarray:
+    """The last rt_render_multi_device frame as an (H, W, 3) host array (waits for it)."""
+    be = _lib.load()
+    out = np.zeros((H, W, 3), dtype=np.float64)
+    if be.lib.rt_multi_copy_frame(b.h, out.ctypes.data, out.size) != 0:
+        raise RenderError(_err(be))
+    return out
+
+
 def last_multi_ms(b: SceneBuilder) -> dict:
     be = _lib.load()
     ms = (C.c_double * 4)()

@@ -297,11 +297,12 @@ def load_image_rgb8(path: str):
 
 
 def load_earthmap():
-    """The reference's earth texture (src/main.rs:248,491-495): tests/golden/earthmap.jpg is a byte copy of its 1024x512 baseline
+    """The reference's earth texture (src/main.rs:248,491-495): assets/earthmap.jpg is a byte copy of its 1024x512 baseline
     4:4:4 asset, decoded by the library's own JPEG ingest (csrc/rt_jpeg.cpp) -> (rgb8 bytes, 1024, 512)."""
     return load_image_rgb8(asset_path("earthmap.jpg"))
 
 
 def asset_path(name: str) -> str:
-    """Committed data fixtures (tests/golden/): the reference's assets cannot be read at run time."""
-    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", name)
+    """Data assets shipped with the package (raytracinginrust_amd/assets/: byte copies of the reference's earthmap.jpg and teapot.obj,
+    which cannot be read from /root/reference at run time)."""
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets", name)

@@ -39,6 +39,41 @@ WORKLOADS = {
 BYTES_PER_SAMPLE = {"C1": 5158.1, "C2": 1473.4, "C3": 2988.0, "C4": 2160.2, "C5": 1039.8}
 
 
+# f64 operations per sample by kind: what the reference's arithmetic executes per camera path, counted by the op-counting build of
+# the CPU oracle (oracle/orc_opcount.h: `double` replaced by a counting stand-in; same samples) on each workload's own pixel grid under
+# the default seed (tests/sweeps/measure_ops_per_sample.py, round 3: C1 at 16 spp, C2/C3 at 4, C4 at 2, C5 at 1; kinds that never occur are left out).  ONE committed table per workload; bench.py prices it against the
+# f64 VALU issue peak at every N and never re-measures it.
+F64_OPS_PER_SAMPLE = {
+    "C1": {"add": 973.23, "mul": 992.4, "div": 440.41, "sqrt": 25.23, "cmp": 819.77, "minmax": 795.85, "sin": 3.1, "cos": 1.16, "atan2": 2.51, "acos": 2.51, "negabs": 12.27, "cvt": 1501.51},
+    "C2": {"add": 276.99, "mul": 247.13, "div": 95.28, "sqrt": 12.6, "cmp": 155.5, "minmax": 1.64, "sin": 0.82, "cos": 0.82, "negabs": 3.81, "cvt": 315.15},
+    "C3": {"add": 952.16, "mul": 1032.77, "div": 250.74, "sqrt": 71.61, "cmp": 427.21, "minmax": 308.08, "sin": 0.79, "cos": 0.65, "atan2": 6.97, "acos": 6.97, "log": 2.57, "floor": 5.82, "negabs": 36.92, "cvt": 909.83},
+    "C4": {"add": 522.01, "mul": 532.74, "div": 202.38, "sqrt": 14.54, "cmp": 328.95, "minmax": 244.48, "sin": 0.97, "cos": 0.97, "negabs": 2.94, "cvt": 683.31},
+    "C5": {"add": 195.44, "mul": 167.35, "div": 62.42, "sqrt": 7.66, "cmp": 111.29, "minmax": 0.93, "sin": 0.46, "cos": 0.46, "negabs": 2.15, "cvt": 196.37},
+}
+
+# What one operation of each kind costs in f64 VALU issue slots, in units of one full-rate f64 instruction (add / mul / compare /
+# min / max: 1).  Division and square root from the instruction costs measured on this chip (tools/ubench: f64 FMA 5, divide 62,
+# sqrt 89 cycles per wave-instruction -> 12.4, 17.8); libm-class functions at the length of their device polynomial paths
+# (argument reduction + minimax kernel), rounded; sign flips / |x| are source modifiers and int<->f64 conversions are not f64
+# arithmetic: 0.  The path has no fused multiply-adds (-ffp-contract=off, as rustc), so one issue slot carries ONE flop per lane.
+VALU_OP_WEIGHTS = {"add": 1.0, "mul": 1.0, "cmp": 1.0, "minmax": 1.0, "floor": 1.0, "div": 12.4, "sqrt": 17.8,
+                   "sin": 50.0, "cos": 50.0, "tan": 70.0, "atan": 40.0, "atan2": 60.0, "acos": 50.0, "log": 45.0, "log2": 45.0, "pow": 120.0,
+                   "negabs": 0.0, "cvt": 0.0}
+# 256 CUs x 4 SIMDs x 16 f64 lanes per clock x 2.4 GHz = 39.3e12 lane-operations per second: the chip's f64 vector peak (78.6 TFLOP/s
+# spec, which counts an FMA as two) for a path without FMAs.
+F64_VALU_PEAK_OPS = 39.3e12
+
+
+def valu_ops(per_kind: dict) -> float:
+    """f64 VALU issue-equivalents per sample of a per-kind operation table."""
+    return sum(VALU_OP_WEIGHTS[k] * v for k, v in per_kind.items())     # C1 9981, C2 2169, C3 8064, C4 4494, C5 1431
+
+
+def flops(per_kind: dict) -> float:
+    """Plain f64 operation count per sample (every arithmetic operation, division, square root and libm call counted once)."""
+    return sum(v for k, v in per_kind.items() if k not in ("negabs", "cvt"))
+
+
 def build(w: Workload, backend, earth=None):
     aspect = w.W / w.H
     if w.scene == "cornell":

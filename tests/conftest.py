@@ -8,6 +8,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def golden_path(name):
+    """A committed test fixture under tests/golden/ (oracle outputs, small decoder inputs).  The reference's own data assets that the
+    workloads need at run time ship with the package: raytracinginrust_amd/assets/, `scenes.asset_path`."""
+    return os.path.join(ROOT, "tests", "golden", name)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
 
@@ -28,7 +34,7 @@ def pbe():
 
 @pytest.fixture(scope="session")
 def earth():
-    """The reference's own 1024x512 earth texture (tests/golden/earthmap.jpg = its earthmap.jpg, src/main.rs:491-495), decoded by
+    """The reference's own 1024x512 earth texture (raytracinginrust_amd/assets/earthmap.jpg = its earthmap.jpg, src/main.rs:491-495), decoded by
     the library's JPEG ingest -> (bytes, w, h)."""
     from raytracinginrust_amd import scenes
     return scenes.load_earthmap()

@@ -1,4 +1,5 @@
-"""Makes the data fixtures under tests/golden/ from the reference's asset files (run once, in the build
+"""Makes the data assets under raytracinginrust_amd/assets/ (teapot.obj, earthmap.jpg: shipped with the package) and the small decoder
+fixtures under tests/golden/ from the reference's asset files (run once, in the build
 container where /root/reference is mounted; the GPU box only sees the committed outputs).
 
   teapot.obj            byte copy of /root/reference/teapot.obj (Utah teapot mesh: 530 v, 1024 f) — input data
@@ -12,10 +13,12 @@ container where /root/reference is mounted; the GPU box only sees the committed 
 import os, shutil
 from PIL import Image
 here = os.path.dirname(os.path.abspath(__file__))
-shutil.copyfile("/root/reference/teapot.obj", os.path.join(here, "teapot.obj"))
+assets = os.path.join(os.path.dirname(os.path.dirname(here)), "raytracinginrust_amd", "assets")
+os.makedirs(assets, exist_ok=True)
+shutil.copyfile("/root/reference/teapot.obj", os.path.join(assets, "teapot.obj"))
 # earthmap.jpg: byte copy of the reference's texture asset (1024x512 baseline 4:4:4 JPEG, loaded at src/main.rs:248,491-495) — the
 # input data of BASELINE config 3; decoded at run time by the library's own JPEG ingest (csrc/rt_jpeg.cpp)
-shutil.copyfile("/root/reference/earthmap.jpg", os.path.join(here, "earthmap.jpg"))
+shutil.copyfile("/root/reference/earthmap.jpg", os.path.join(assets, "earthmap.jpg"))
 im = Image.open("/root/reference/earthmap.jpg").convert("RGB")
 assert im.size == (1024, 512)
 im.resize((256, 128), Image.BOX).save(os.path.join(here, "earthmap_256x128.png"), optimize=True)

@@ -21,6 +21,32 @@ CASES = {  # name: (W, H, spp, depth)
     "teapot": (32, 18, 8, 50),
 }
 
+# BASELINE configs 2-5 on their own pixel grids at the first k samples of every pixel (the full config's RNG streams 0..k-1): sums over
+# 16x16-pixel blocks of the oracle's per-pixel sums (the frames themselves are 15-199 MB), the non-finite count per block.
+GRID_SPP = {"C2": 16, "C3": 4, "C4": 2, "C5": 1}
+
+
+def block_sums(img, blk=16):
+    H, W, _ = img.shape
+    fin = np.isfinite(img).all(axis=-1)
+    v = np.where(fin[..., None], img, 0.0)
+    ys, xs = np.arange(0, H, blk), np.arange(0, W, blk)
+    return (np.add.reduceat(np.add.reduceat(v, ys, axis=0), xs, axis=1),
+            np.add.reduceat(np.add.reduceat((~fin).astype(np.int64), ys, axis=0), xs, axis=1))
+
+
+def make_grid_goldens(be, earth):
+    from raytracinginrust_amd import workloads
+    for key, spp in GRID_SPP.items():
+        w = workloads.WORKLOADS[key]
+        b, cam, bg = workloads.build(w, be, earth)
+        out = orc.render(b, cam, bg, w.W, w.H, spp, w.max_depth, seed=scenes.DEFAULT_SEED)
+        sums, bad = block_sums(out)
+        np.savez_compressed(os.path.join(HERE, f"oracle_grid_{key}.npz"), block_sums=sums, nonfinite=bad, W=w.W, H=w.H, spp=spp, depth=w.max_depth,
+                            seed=scenes.DEFAULT_SEED)
+        print(key, sums.shape, float(sums.sum()) / (w.W * w.H * spp), int(bad.sum()))
+
+
 if __name__ == "__main__":
     earth = scenes.load_earthmap()          # the reference's own 1024x512 texture, decoded by the library's JPEG ingest
     be = orc.load()
@@ -30,3 +56,4 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, f"oracle_{name}.npz"), rgb_sum=out, W=W, H=H, spp=spp, depth=depth,
                             seed=scenes.DEFAULT_SEED, bytes_per_sample=orc.algorithmic_bytes_per_sample(cnt, spp))
         print(name, out.shape, float(out.mean()) / spp, orc.algorithmic_bytes_per_sample(cnt, spp))
+    make_grid_goldens(be, earth)

@@ -26,7 +26,13 @@ def test_bench_line_has_the_contract_keys():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    if r["bound"] == "hbm":                                      # rounds 1-2: BASELINE's algorithmic-bytes model as the headline
+        assert r["unit"] == "GB/s"
+    else:                                                        # round 3 on: the bound that is real, f64 VALU issue; the model beside it
+        assert r["bound"] == "f64_valu" and r["frac"] <= 1.0 and "model_hbm" in r
+        m = r["model_hbm"]
+        assert m["exceeds_hbm_peak"] == (m["achieved_GBps"] > m["peak_GBps"]) and abs(m["ratio"] - m["achieved_GBps"] / m["peak_GBps"]) < 1e-9
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -38,10 +44,18 @@ def test_bench_line_is_self_consistent():
     samples = 800 * 800 * 1024
     assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     r = d["roofline"]
-    assert abs(r["achieved"] - r["bytes_per_sample"] * samples / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    if r["bound"] == "hbm":
+        assert abs(r["achieved"] - r["bytes_per_sample"] * samples / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        alg = r["algorithmic_bytes_per_launch"]
+    else:
+        from raytracinginrust_amd import workloads
+        assert r["ops_per_sample"] == workloads.valu_ops(workloads.F64_OPS_PER_SAMPLE["C2"])
+        assert abs(r["achieved"] - r["ops_per_sample"] * r["samples_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+        assert r["peak"] == workloads.F64_VALU_PEAK_OPS / 1e12
+        alg = r["model_hbm"]["algorithmic_bytes_per_launch"]
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.001            # the kernel is inside the step
     if r["traffic"] is not None:                                 # only quoted from a PMC profile of the same kernel build
-        assert r["framebuffer_atomic_bytes_per_launch"] < r["traffic"] < r["algorithmic_bytes_per_launch"]
+        assert r["framebuffer_atomic_bytes_per_launch"] < r["traffic"] < alg
 
 
 def test_bench_line_times_the_other_configs():
@@ -57,7 +71,14 @@ def test_bench_line_times_the_other_configs():
         assert e["bytes_per_sample"] == workloads.BYTES_PER_SAMPLE[key]
         assert abs(e["value"] - w.samples / (e["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * e["value"] and e["steps"] >= 1
         assert e["kernel_ms"] <= e["ms_per_step"] * 1.001
-        assert abs(e["frac"] - e["bytes_per_sample"] * w.samples / (e["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        if d["roofline"]["bound"] == "hbm":
+            assert abs(e["frac"] - e["bytes_per_sample"] * w.samples / (e["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
+        else:
+            ops = workloads.valu_ops(workloads.F64_OPS_PER_SAMPLE[key])
+            assert e["ops_per_sample"] == ops and e["frac"] <= 1.0
+            assert abs(e["frac"] - ops * w.samples / (e["kernel_ms"] * 1e-3) / workloads.F64_VALU_PEAK_OPS) < 1e-9
+            assert abs(e["model_hbm_ratio"] - e["bytes_per_sample"] * w.samples / (e["kernel_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-9
     c = d["cpu_baseline"]
     assert "reference_shaped" in c and c["reference_shaped"]["value"] > 0 and "flags" in c and "compiler" in c
-    assert d["roofline"]["bytes_per_sample"] == workloads.BYTES_PER_SAMPLE["C2"]
+    r = d["roofline"]
+    assert (r["bytes_per_sample"] if r["bound"] == "hbm" else r["model_hbm"]["bytes_per_sample"]) == workloads.BYTES_PER_SAMPLE["C2"]

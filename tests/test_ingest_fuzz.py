@@ -8,6 +8,8 @@ import random
 import numpy as np
 import pytest
 
+from conftest import golden_path
+
 from raytracinginrust_amd import scenes
 
 
@@ -134,8 +136,8 @@ def test_obj_ingest_mutation_fuzz(pbe):
 
 def _jpeg_cases():
     """Hand-made hostile streams (the classes ADVICE.md / VERDICT.md name) + seeded mutations of real files."""
-    real = open(scenes.asset_path("earthmap_256x128_444.jpg"), "rb").read()
-    grey = open(scenes.asset_path("earthmap_256x128_grey.jpg"), "rb").read()
+    real = open(golden_path("earthmap_256x128_444.jpg"), "rb").read()
+    grey = open(golden_path("earthmap_256x128_grey.jpg"), "rb").read()
     cases = [b"", b"\xff", b"\xff\xd8", b"\xff\xd8\xff", b"\xff\xd8\xff\xff\xff\xff", b"\xff\xd8" + b"\xff" * 64,
              b"\xff\xd8\xff\xd9", b"\xff\xd8\xff\xe0\x00", b"\xff\xd8\xff\xe0\xff\xff" + b"\x00" * 10]
     # truncation at every marker boundary and at a spread of other offsets

@@ -48,6 +48,85 @@ def test_render_multi_tile_arithmetic_with_virtual_ranks(pbe, ranks, tile, monke
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 4])
+def test_render_multi_device_leaves_the_frame_on_the_device(pbe, ranks, monkeypatch):
+    """rt_render_multi_device / rt_multi_sync / rt_multi_copy_frame: the frame stays in the first device's memory (what bench.py's
+    in-process N > 1 mode times), consecutive calls reuse the scene's buffers, timings settle at the sync."""
+    import torch
+    b, cam, bg = scenes.cornell_box(pbe, aspect_ratio=16 / 9)
+    W, H, spp, depth = 160, 90, 8, 50
+    ref = R.render(b, cam, bg, W, H, spp, depth)
+    if ranks > 1:
+        monkeypatch.setenv("RT_MULTI_VIRTUAL_RANKS", str(ranks))
+    dev_before = torch.cuda.current_device()
+    ptrs = set()
+    for _ in range(3):                                   # back-to-back frames without a host wait in between
+        ptrs.add(R.render_multi_device(b, cam, bg, W, H, spp, depth, device_mask=1))
+    R.multi_sync(b)
+    assert len(ptrs) == 1 and 0 not in ptrs and torch.cuda.current_device() == dev_before
+    got = R.multi_frame(b, W, H)
+    assert np.all(np.abs(got - ref) <= 1e-12 * (spp + np.abs(ref)))
+    ms = R.last_multi_ms(b)
+    assert ms["slowest_kernel_ms"] > 0 and ms["call_ms"] > 0 and ms["unpermute_ms"] > 0
+    n = R.kernel_time_total(b)[1]
+    assert n == 1 + 3 * ranks                            # every rank's launch is timed
+
+
+@pytest.mark.gpu
+def test_render_multi_failure_leaves_nothing_behind(pbe, monkeypatch):
+    """A rank that fails after others were launched (test hook RT_MULTI_FAIL_RANK): the call returns an error with the rank in the
+    message, nothing stays in flight, no temporary leaks (device memory in use does not grow over repeated failures), the caller's
+    current device is untouched, and the next call renders the right frame."""
+    import torch
+    b, cam, bg = scenes.cornell_box(pbe, aspect_ratio=16 / 9)
+    W, H, spp, depth = 160, 90, 8, 50
+    ref = R.render(b, cam, bg, W, H, spp, depth)
+    monkeypatch.setenv("RT_MULTI_VIRTUAL_RANKS", "4")
+    good = R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)            # allocates the scene's multi buffers once
+    torch.cuda.synchronize()
+    dev_before = torch.cuda.current_device()
+    free0 = torch.cuda.mem_get_info()[0]
+    monkeypatch.setenv("RT_MULTI_FAIL_RANK", "2")
+    for _ in range(10):
+        with pytest.raises(R.RenderError, match="rank 2.*injected failure"):
+            R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
+        with pytest.raises(R.RenderError, match="injected failure"):
+            R.render_multi_device(b, cam, bg, W, H, spp, depth, device_mask=1)
+    R.multi_sync(b)                                      # nothing pending: returns at once
+    torch.cuda.synchronize()
+    assert torch.cuda.current_device() == dev_before
+    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
+    monkeypatch.delenv("RT_MULTI_FAIL_RANK")
+    again = R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
+    assert np.array_equal(again, good) and np.all(np.abs(again - ref) <= 1e-12 * (spp + np.abs(ref)))
+    with pytest.raises(R.RenderError, match="RT_WAVEFRONT"):
+        R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1, flags=R.RT_WAVEFRONT)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_runs_in_process_without_a_launcher(gpus):
+    """`python bench.py --gpus N` with no launcher (what the driver's SCALE run may use): the in-process mode through
+    rt_render_multi_device, here with N virtual ranks on the one GPU; the line keeps the contract."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RT_MULTI_VIRTUAL_RANKS=str(gpus))
+    env.pop("WORLD_SIZE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--also", "C1",
+                        "--cpu-spp", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == gpus and d["steps"] == 2 and d["scaling"] == "strong" and d["config"]["mode"] == "inproc"
+    assert "rt_render_multi_device" in d["config"]["parallelism"] and "VIRTUAL" in d["config"]["parallelism"]
+    assert abs(d["value"] - 800 * 800 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "f64_valu" and 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"] is None
+    assert set(d["multi_ms_last_frame"]) == {"slowest_kernel_ms", "gather_ms", "unpermute_ms", "call_ms"}
+    assert 0.4 < d["mean_radiance"] < 0.55 and "C1" in d["workloads"]
+
+
+@pytest.mark.gpu
 def test_render_multi_all_devices(pbe):
     n = R.device_count()
     if n < 2:
