@@ -123,7 +123,7 @@ def test_bench_runs_in_process_without_a_launcher(gpus):
     assert abs(d["value"] - 800 * 800 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "f64_valu" and 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"] is None
     assert set(d["multi_ms_last_frame"]) == {"slowest_kernel_ms", "gather_ms", "unpermute_ms", "call_ms"}
-    assert 0.4 < d["mean_radiance"] < 0.55 and "C1" in d["workloads"]
+    assert 0.13 < d["mean_radiance"] < 0.18 and "C1" in d["workloads"]          # the Cornell frame's mean per channel (oracle: 0.155)
 
 
 @pytest.mark.gpu
