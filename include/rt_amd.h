@@ -56,6 +56,11 @@ enum {
                               path as soon as their search ends / hit record + material — instead of one persistent kernel.
                               rt_render_device is synchronous with it; its path pools take up to 4 GB (never more than a quarter of
                               the device's free memory) and are released when the scene is edited or destroyed.               */
+    RT_DEFER_BVH = 256,    /* scheduling only, same samples (lock-step BVH kernels): a lane whose ray enters a BVH object that few lanes of its
+                              wavefront enter parks its path in a per-wave ring in device memory and takes another one; once 64 paths
+                              wait at such an object the wavefront walks it for all of them at once.  Chosen automatically where it
+                              pays; this flag forces it on ...                                                     */
+    RT_NO_DEFER_BVH = 512, /* ... and this one off                                                                            */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
                               old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };

@@ -68,7 +68,7 @@ void rt_scene_destroy(rt_scene* sc) {
         free_device_scene(c->dev32);
         for (Scene::LaunchSlot& l : c->slots) {
             if (l.recorded) (void)hipEventSynchronize((hipEvent_t)l.ev_stop);
-            free_dev(l.d_queue); free_dev(l.d_stats);
+            free_dev(l.d_queue); free_dev(l.d_stats); free_dev(l.d_defer);
             if (l.ev_start) (void)hipEventDestroy((hipEvent_t)l.ev_start);
             if (l.ev_stop) (void)hipEventDestroy((hipEvent_t)l.ev_stop);
         }
@@ -484,18 +484,35 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
         if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size()) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
+    // Deferred BVH entry (scheduling only): for the reference-order lock-step kernels of scenes in which a BVH object stands beside
+    // other top-level objects (a BVH that IS the world is entered by every ray: nothing to defer)
+    {
+        size_t n_bvh_objects = 0;
+        for (const DObject& ob : f.objects) n_bvh_objects += (ob.geom_kind == G_BVH && ob.medium < 0) ? 1u : 0u;
+        const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && n_bvh_objects != 0 && n_bvh_objects <= RT_MAX_DEFER_RINGS && n_bvh_objects == f.n_defer_rings &&
+                         f.objects.size() > 1 && !(flags & (RT_NEAR_FIRST_BVH | RT_WAVEFRONT));
+        if (!can || (flags & RT_NO_DEFER_BVH)) out &= ~(uint32_t)RT_DEFER_BVH;
+        if (out & RT_DEFER_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
+        if (out & RT_PERSISTENT_BVH) out &= ~(uint32_t)RT_DEFER_BVH;
+    }
     return out;
 }
 
 // BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
 // queues and stacks; 0 for the list-scene kernels.
+// bytes from one cached BVH node to the next in LDS (see pathtrace_kernel)
+template <typename T> size_t lds_node_stride() {
+    size_t stride = sizeof(DBvhNode<T>);
+    if (const char* v = std::getenv("RT_NODE_LDS_PAD")) { const long n = std::strtol(v, nullptr, 10); if (n == 16 || n == 0) stride = sizeof(DBvhNode<T>) + (size_t)n; }   // A/B runs only
+    return stride;
+}
 template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop, uint32_t stack_depth) {
     if (!g.one_per_cu || f.bvh.empty()) return 0u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     if (lds_total < 65536u) lds_total = 65536u;
-    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, sizeof(DBvhNode<T>));
-    if (fixed + sizeof(DBvhNode<T>) > lds_total) return 0u;
-    size_t room = (lds_total - fixed) / sizeof(DBvhNode<T>);
+    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, lds_node_stride<T>());
+    if (fixed + lds_node_stride<T>() > lds_total) return 0u;
+    size_t room = (lds_total - fixed) / lds_node_stride<T>();
     // RT_NODE_CACHE_MAX (tests, A/B runs): stage at most that many nodes (0 = every node comes from global memory); scheduling only
     if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
     return (uint32_t)std::min(room, f.bvh.size());
@@ -509,7 +526,7 @@ template <typename T>
 int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const LaunchShape&, const hipDeviceProp_t& prop,
                      uint64_t n_local_px, hipStream_t stream) {
     // the wavefront kernels are the lock-step-family instantiations (never the persistent-traversal one): their workgroup shape
-    P.flags &= ~(uint32_t)RT_PERSISTENT_BVH;
+    P.flags &= ~(uint32_t)(RT_PERSISTENT_BVH | RT_DEFER_BVH);
     const LaunchShape shape = pathtrace_shape(f.feats, P.flags);
     // the real (unpadded) local pixels are a prefix of the local range: tile t = rank + q * world grows with q
     const uint64_t n_px = (uint64_t)P.W * P.H;
@@ -550,6 +567,7 @@ int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const
     size_t room = lds_total > stacks ? (lds_total - stacks) / sizeof(DBvhNode<T>) : 0;
     if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
     P.n_cached = (uint32_t)std::min(room, f.bvh.size());
+    P.lds_node_stride = (uint32_t)sizeof(DBvhNode<T>);
     const size_t shmem = (size_t)P.n_cached * sizeof(DBvhNode<T>) + stacks;
     uint64_t n_alive = 0, next_sample = 0;
     int cur = 0;
@@ -648,7 +666,8 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         if (n == 16 || n == 32 || n == 64) { shape.queue_entries = (uint32_t)n; P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth); }
     }
     P.queue_entries = shape.queue_entries;
-    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
+    P.lds_node_stride = (uint32_t)lds_node_stride<T>();
+    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, lds_node_stride<T>());
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel (LDS: " + std::to_string(shmem) + " bytes per workgroup)");
     const uint64_t waves_per_block = shape.threads / 64u;
@@ -678,6 +697,23 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         P.n_chunks = (uint32_t)n_chunks64;
     }
 
+    P.defer_ring = nullptr; P.defer_capacity = 0u; P.defer_dense = 0u; P.defer_rings = 0u; P.defer_stop = 1u;
+    if (P.flags & RT_DEFER_BVH) {
+        // per wavefront of the grid and bare BVH object one ring of parked paths: 256 slots of 128 bytes (up to 63 waiting for the walk +
+        // the 64 just walked + what a step parks on top); 128 MB per object for a chip-filling grid
+        P.defer_capacity = 256u;
+        P.defer_rings = f.n_defer_rings;
+        P.defer_dense = 48u;
+        P.defer_stop = 20u;
+        if (const char* v = std::getenv("RT_DEFER_STOP")) { const long n = std::strtol(v, nullptr, 10); if (n >= 1 && n <= 64) P.defer_stop = (uint32_t)n; }      // A/B runs, tests: 1 = walks run to their end
+        if (const char* v = std::getenv("RT_DEFER_DENSE")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && n <= 65) P.defer_dense = (uint32_t)n; }   // A/B runs, tests: 0 = never park, 65 = always
+        const size_t need = (size_t)n_blocks * waves_per_block * P.defer_rings * P.defer_capacity * 16u * sizeof(double);
+        if (slot->defer_bytes < need) {
+            if (slot->d_defer) { (void)hipFree(slot->d_defer); slot->d_defer = nullptr; slot->defer_bytes = 0; }
+            HIP_OK(hipMalloc(&slot->d_defer, need)); slot->defer_bytes = need;
+        }
+        P.defer_ring = (double*)slot->d_defer;
+    }
     HIP_OK(hipMemsetAsync(slot->d_queue, 0, 64, stream));
     HIP_OK(hipMemsetAsync(slot->d_stats, 0, RT_STATS_BYTES, stream));
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)n_local_px * 3 * sizeof(double), stream));
@@ -753,8 +789,8 @@ int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     int bpc;
     const uint32_t sd = stack_depth_of(s.flat, eff);
-    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), sizeof(DBvhNode<float>)));
-    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd), sizeof(DBvhNode<double>)));
+    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), lds_node_stride<float>()));
+    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd), lds_node_stride<double>()));
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;

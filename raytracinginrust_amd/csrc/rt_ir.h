@@ -42,8 +42,11 @@ enum Feat : uint32_t {
     F_PBR = 1u << 6,        // principled material (PBR) + PDF::BRDF
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
-    F_PERSIST = 1u << 8     // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
+    F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
+    F_DEFER = 1u << 9,      // not a scene feature: lock-step loop with deferred entry into sparsely entered BVH objects (RT_DEFER_BVH)
+    F_NO_PLAIN_BVH = 1u << 10   // (inside the F_DEFER kernels) object_hit without the arm for bare BVH objects: the caller walks those
 };
+static const uint32_t RT_MAX_DEFER_RINGS = 4u;     // deferrable BVH objects per scene (one ring of parked paths per object and wavefront)
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count, node.c = rank in DFS
                                                    //       preorder (= the reference's visiting order: resolves exact-t ties in near-first mode);
@@ -58,7 +61,7 @@ template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad;
 template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
-struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
+struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };   // pad0: a bare BVH object's ring of parked paths (F_DEFER kernels)
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 template <typename T> struct alignas(16) DMaterial { uint32_t kind, tex; T albedo[3]; T param; };   // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
@@ -91,6 +94,7 @@ template <typename T> struct KParams {
     const uint8_t* image_bytes;
     uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS: 0 in the reference's traversal order (skip links), the tree depth for near-first
     uint32_t queue_entries;        // camera paths each wave's LDS queue holds (16, 32 or 64; 80 B each)
+    uint32_t lds_node_stride;      // bytes from one cached node to the next in LDS (the record size, or 16 more: see pathtrace_kernel)
     uint32_t n_cached;             // BVH nodes [0, n_cached) are copied into LDS by every workgroup at launch (depth order: the top levels)
     uint32_t bvh_tame;             // every BVH box is finite, below 1e300 in magnitude and has min <= max: rays that are tame too may
                                    // take the NaN-free form of AABB::hit (rt_kernel.hip: box_inside_tame) — same answers
@@ -114,6 +118,10 @@ template <typename T> struct KParams {
     // BVH scenes (persistent traversal): a traversal pass starts once trav_hi lanes are inside a BVH and runs until fewer
     // than trav_lo are still walking
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
+    // Deferred BVH entry: rings of parked paths, defer_rings per wavefront (one per bare BVH object, DObject::pad0) of defer_capacity slots (a power of two) each;
+    // an object that at least defer_dense lanes of the wave enter is walked on the spot.
+    // A walk is suspended once fewer than defer_stop lanes are still in it; the stragglers are walked on with the next batch.
+    double* defer_ring; uint32_t defer_capacity, defer_dense, defer_rings, defer_stop;
 };
 
 // Wavefront backend (RT_WAVEFRONT): the paths in flight live in two pools of `P` records in HBM, used in turn: a round reads the live

@@ -416,7 +416,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 // the ids below n_cached are the top levels of every tree, where most visits go: each workgroup holds them in LDS (one copy per
 // CU: the BVH kernels run one workgroup per CU) and a visit there is four ds_read_b128 instead of four global loads.
 template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t node) {
-    if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * (uint32_t)sizeof(DBvhNode<T>));
+    if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * P.lds_node_stride);
 #ifdef RT_NODE_SOA      // measurement build only: the north_star's field-wise structure-of-arrays node layout
     DBvhNode<T> nd;
     const uint32_t n = P.n_bvh;
@@ -429,8 +429,13 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
 #endif
 }
 
+// `root` is the node a lane's walk starts (or, after a suspension, goes on) at.  `stop_below` > 1 (reference order only) suspends the
+// search as soon as fewer lanes than that are still walking — after a leaf step, so no leaf is pending: the stragglers' next node comes
+// back in `next_node` (0xFFFFFFFF: finished) and their running closest hit in t_out / prim_out, and the caller resumes them later, with
+// company, from exactly that state (trace_deferred).
 template <typename T, uint32_t FEATS>
-DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
+DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack,
+                    uint32_t stop_below = 1u, uint32_t* next_node = nullptr) {
     V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
     T closest = t_max;
     bool any = false;
@@ -485,15 +490,17 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                 bvh_accept(near_first, t, closest, leaf_node, best_leaf)) { closest = t; prim_out = prim; any = true; best_leaf = leaf_node; }
             have_leaf = false;
         }
-        if (__ballot(node != DONE) == 0) break;          // every lane of the wave is finished
+        if ((uint32_t)__popcll(__ballot(node != DONE)) < stop_below) break;          // every lane of the wave is finished (or few enough are left)
     }
+    if (next_node) *next_node = node;
     t_out = closest;
     return any;
 }
 
 template <typename T, uint32_t FEATS>
-DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
-    return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack);
+DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack,
+                 uint32_t stop_below = 1u, uint32_t* next_node = nullptr) {
+    return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack, stop_below, next_node);
 }
 
 // ------------------------------------------------------------------ wrapper chain (translate.rs, rotate.rs, hit.rs FlipNormal)
@@ -532,7 +539,8 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
         T t; uint32_t prim;
-        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        // (F_NO_PLAIN_BVH: the caller walks bare BVH objects itself — trace_deferred — so that arm is compiled out of this copy)
+        if (geom_hit<T, (FEATS & F_NO_PLAIN_BVH) ? (FEATS & ~(uint32_t)F_BVH) : FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     } else {
         // ConstantMedium::hit, medium.rs:27-61
         T t1, t2; uint32_t p1, p2;
@@ -558,10 +566,37 @@ template <typename T, uint32_t FEATS>
 DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack) {
     T closest = Lim<T>::inf();
     bool any = false;
+#ifdef RT_DIAG_OBJ      // diagnostic build only: where world.hit's time goes by object class, and how many lanes enter each BVH object:
+                        // stats[3] wave-cycles in BVH objects without wrappers, [4] in BVH objects behind wrappers, [5] in all other objects,
+                        // [6] / [7] lanes whose ray passes the root box of the former / latter, [8] calls, [12] lanes in the calls
+    unsigned long long dg[3] = {0, 0, 0}, dl[2] = {0, 0};
+#endif
     for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
         const DObject ob = ld_obj(P.objects + oi);
+#ifdef RT_DIAG_OBJ
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
+        if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) {
+            RayT<T> r = ray;
+            for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+            const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
+            dl[ob.n_ops ? 1 : 0] += (unsigned long long)__popcll(__ballot(box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest)));
+        }
+#endif
         object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
+#ifdef RT_DIAG_OBJ
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
+        dg[ob.geom_kind == G_BVH ? (ob.n_ops ? 1 : 0) : 2] += t1 - t0;
+#endif
     }
+#ifdef RT_DIAG_OBJ
+    {
+        const unsigned long long ex = __ballot(true);
+        if (P.stats && __builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)) == 0u) {
+            atomicAdd(&P.stats[3], dg[0]); atomicAdd(&P.stats[4], dg[1]); atomicAdd(&P.stats[5], dg[2]);
+            atomicAdd(&P.stats[6], dl[0]); atomicAdd(&P.stats[7], dl[1]); atomicAdd(&P.stats[8], 1ull); atomicAdd(&P.stats[12], (unsigned long long)__popcll(ex));
+        }
+    }
+#endif
     t_hit = closest;
     return any;
 }
@@ -1329,6 +1364,254 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 #endif
 }
 
+// ------------------------------------------------------------------ BVH scenes: lock-step loop with deferred BVH entry
+// A BVH object that stands beside others is entered by a minority of a wave's lanes — *measured* (round 3, -DRT_DIAG_OBJ) per
+// `world.hit` call of the final scene: 27 of 59 lanes pass the root box of the ground boxes' tree, 12 that of the sphere cluster's;
+// teapot room: 26 of 63 — and those then walk a hundred nodes while the others wait: 88 % of that scene's `world.hit` time, half the
+// frame, at a quarter of the lanes.  Here a lane whose ray passes the root box of such an object (fewer than P.defer_dense lanes of the
+// wave do) does not walk it on the spot.  It PARKS its whole path — ray, closest hit so far, throughput, RNG state, pixel, sample: 128
+// bytes — in the wave's ring for that object in device memory.  Once 64 paths wait there, the wave walks the tree for all of them at
+// once, right at that object's place in the list and through the same code that walks it when most lanes enter; the results go back
+// to the ring.  A lane that has just parked takes a walked path out of the ring in exchange and goes on with it — the objects behind
+// the BVH, the material — so no lane waits for a walk and no lane idles after parking.
+// A path's own sequence of operations (objects in push order, bbox / left / right, shrinking t_max, RNG draws) is untouched, so every
+// sample is bit-identical to the plain lock-step loop; what changes is which lane runs which part of it when, i.e. the order in which a
+// pixel's samples are summed (deviation D3).
+// Rings: one per deferrable object (DObject::pad0, at most RT_MAX_DEFER_RINGS) and wave, `defer_capacity` slots, 16 columns of 8
+// bytes, column-major ([column][slot]: consecutive lanes use consecutive slots).  Indices grow monotonically, slot = index &
+// (capacity - 1): [done, wait) walked, waiting for a lane; [wait, tail) parked, waiting for the walk.  Lane r of the wave keeps ring
+// r's three indices (read with v_readlane).  A walk reads what earlier instructions of the same wave stored and vice versa: ordered
+// by workgroup-scope fences.
+struct DeferCtl { uint32_t done, wait, tail; };
+// one parked path: the world-space ray, the closest hit of its list search so far (any_hit rides on the depth word), throughput, RNG
+// state, bounces left, pixel, sample, and the node its walk of this tree starts or goes on at
+enum : uint32_t { DC_OX = 0, DC_OY, DC_OZ, DC_DX, DC_DY, DC_DZ, DC_TM, DC_CLOSEST, DC_BX, DC_BY, DC_BZ, DC_RNG01, DC_RNG23, DC_ID, DC_DEPTH_PX, DC_S_NODE, DC_COLS };
+static_assert(DC_COLS == 16u, "a parked path is 16 columns of 8 bytes");
+DEV double pack2(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo)); }
+DEV void unpack2(double x, uint32_t& lo, uint32_t& hi) { const unsigned long long u = (unsigned long long)__double_as_longlong(x); lo = (uint32_t)u; hi = (uint32_t)(u >> 32); }
+DEV uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
+template <typename T>
+DEV void defer_store(double* b, uint32_t C, const RayT<T>& ray, T closest, HitId id, bool any_hit, V3<T> beta, const Rng& rng, uint32_t depth_left,
+                     uint32_t path_px, uint32_t path_s, uint32_t node) {
+    b[DC_OX * C] = (double)ray.o.x; b[DC_OY * C] = (double)ray.o.y; b[DC_OZ * C] = (double)ray.o.z;
+    b[DC_DX * C] = (double)ray.d.x; b[DC_DY * C] = (double)ray.d.y; b[DC_DZ * C] = (double)ray.d.z;
+    b[DC_TM * C] = (double)ray.tm; b[DC_CLOSEST * C] = (double)closest;
+    b[DC_BX * C] = (double)beta.x; b[DC_BY * C] = (double)beta.y; b[DC_BZ * C] = (double)beta.z;
+    b[DC_RNG01 * C] = pack2(rng.s0, rng.s1); b[DC_RNG23 * C] = pack2(rng.s2, rng.s3);
+    b[DC_ID * C] = pack2(id.obj, id.prim);
+    b[DC_DEPTH_PX * C] = pack2(depth_left | (any_hit ? 0x80000000u : 0u), path_px);
+    b[DC_S_NODE * C] = pack2(path_s, node);
+}
+
+template <typename T, uint32_t FEATS>
+DEV void trace_deferred(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack, double* acc_col, double* rings) {
+    WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
+    DeferCtl ctl; ctl.done = ctl.wait = ctl.tail = 0u;
+    const uint32_t C = P.defer_capacity;
+    const uint32_t DONE = 0xFFFFFFFFu;
+    // per-lane path state
+    bool alive = false;
+    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
+    V3<T> beta = mk<T>(T(0), T(0), T(0));
+    uint32_t depth_left = 0, path_px = 0, path_s = 0;
+    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
+    uint32_t acc_px = NONE_PX;
+    typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
+    acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
+    uint32_t n_nonfinite = 0, n_flush = 0;
+    unsigned long long n_iters = 0, n_active = 0, n_walks = 0, n_walk_lanes = 0, n_parked = 0;
+    DIAG_DECL       // (-DRT_DIAG: [0] new paths + flush, [1] list objects, [2] root tests + parking, [3] tree walks, [4] taking walked paths, [5] hit record + material)
+    DIAG_T0();
+
+    for (;;) {
+        // ---- lanes whose path has ended take the next camera path from the wave's queue
+        uint32_t new_px = 0;
+        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
+        const bool draining = w.queue_done && w.q_count == 0u;       // no camera path left: parked paths are walked as they come
+        if (__ballot(alive || got_new) == 0 && __ballot(lane < P.defer_rings && ctl.tail != ctl.done) == 0) break;    // no path anywhere
+        // ---- lanes moving on to another pixel hand in their partial sum
+        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
+        if (got_new) {
+            if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
+            path_px = new_px;
+            beta = mk<T>(T(1.0), T(1.0), T(1.0));
+            depth_left = P.max_depth;
+            alive = true;
+        }
+        n_iters++;
+        n_active += (unsigned long long)__popcll(__ballot(alive));
+        DIAG_ADD(0);
+
+        // ---- one level of ray_color (main.rs:41-120) for every live lane
+        bool spent = alive && depth_left == 0u;         // main.rs:42-45: the sample is beta * 0
+        bool vacant = false;                            // this lane's path was parked in this iteration and nothing came in exchange
+        T closest = Lim<T>::inf(); HitId id; id.obj = 0; id.prim = 0; bool any_hit = false;
+        // world.hit (main.rs:48): the top-level list in push order (hit.rs:59-71)
+        for (uint32_t oi = 0; oi < P.n_objects; oi++) {
+            const DObject ob = ld_obj(P.objects + oi);
+            const bool act = alive && !spent && !vacant;
+            if (!(ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0))) {
+                if (act) object_hit<T, FEATS | F_NO_PLAIN_BVH>(P, oi, ob, ray, TMin<T>::v(), rng, closest, id, any_hit, stack);
+                DIAG_ADD(1);
+                continue;
+            }
+            // ---- a BVH object.  AABB::hit of the tree's root is what BVH::hit does first (bvh.rs:78): who enters?
+            const uint32_t ring = ob.pad0;
+            double* const base = rings + (size_t)ring * (size_t)(C * DC_COLS);
+            uint32_t h_done = rlane(ctl.done, ring), h_wait = rlane(ctl.wait, ring), tail = rlane(ctl.tail, ring);
+            RayT<T> r = ray;
+            for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+            bool enter;
+            {
+                const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
+                enter = act && box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, TMin<T>::v(), closest);
+            }
+            const unsigned long long em = __ballot(enter);
+            const uint32_t n_enter = (uint32_t)__popcll(em);
+            const uint32_t room = C - (tail - h_done);
+            // most lanes enter (or the ring is full): walk on the spot, as the plain lock-step loop does
+            const bool dense = n_enter >= P.defer_dense || n_enter > room;
+            if (!dense && n_enter != 0u) {
+                if (enter) {
+                    defer_store(base + ((tail + lane_rank(em)) & (C - 1u)), C, ray, closest, id, any_hit, beta, rng, depth_left, path_px, path_s, ob.geom_first);
+                    vacant = true;
+                }
+                tail += n_enter; n_parked += n_enter;
+            }
+            DIAG_ADD(2);
+            const uint32_t n_wait = tail - h_wait;
+            const bool walk = !dense && (n_wait >= 64u || (n_wait != 0u && draining));
+            if (walk || (dense && n_enter != 0u)) {
+                // BVH::hit (bvh.rs:77-91): for the wave's own entering rays, or for the oldest (up to) 64 parked ones.  The walk is
+                // suspended once fewer than defer_stop lanes are still in it: the stragglers go (back) to the ring with the node they
+                // stand at and are walked on together with the next batch — nobody waits for the longest ray of a batch.
+                const uint32_t n_w = n_wait < 64u ? n_wait : 64u;
+                uint32_t stop_below = draining ? 1u : P.defer_stop;
+                if (dense && stop_below > room + 1u) stop_below = room + 1u;          // own stragglers need a slot each
+                RayT<T> tr = r; T tcl = closest; bool part = enter; uint32_t node = ob.geom_first, s_keep = 0;
+                double* wb = base + ((h_wait + lane) & (C - 1u));
+                if (walk) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the stores that parked these paths (this or earlier iterations)
+                    part = lane < n_w;
+                    if (part) {
+                        tr.o = mk<T>((T)wb[DC_OX * C], (T)wb[DC_OY * C], (T)wb[DC_OZ * C]);
+                        tr.d = mk<T>((T)wb[DC_DX * C], (T)wb[DC_DY * C], (T)wb[DC_DZ * C]);
+                        tr.tm = (T)wb[DC_TM * C]; tcl = (T)wb[DC_CLOSEST * C];
+                        unpack2(wb[DC_S_NODE * C], s_keep, node);
+                        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), tr);
+                    }
+                    n_walks++; n_walk_lanes += n_w;
+                }
+                if (!part) { tr.o = mk<T>(T(0), T(0), T(0)); tr.d = mk<T>(T(1.0), T(1.0), T(1.0)); node = DONE; }     // (idle lanes: a tame ray, no node)
+                T t; uint32_t prim, next = DONE;
+                const bool hit = bvh_hit<T, FEATS>(P, node, tr, TMin<T>::v(), tcl, t, prim, stack, stop_below, &next);
+                const bool straggler = part && next != DONE;
+                const unsigned long long sm = __ballot(straggler);
+                if (walk) {
+                    // results into the ring; the batch's slots are re-dealt so that the finished paths come first ([done, wait) grows by
+                    // them) and the stragglers stay at the head of the waiting ones
+                    const unsigned long long fm = __ballot(part && !straggler);
+                    const uint32_t n_fin = (uint32_t)__popcll(fm);
+                    if (sm == 0ull) {
+                        if (part && hit) {
+                            uint32_t dw, px; unpack2(wb[DC_DEPTH_PX * C], dw, px);
+                            wb[DC_CLOSEST * C] = (double)t; wb[DC_ID * C] = pack2(oi, prim); wb[DC_DEPTH_PX * C] = pack2(dw | 0x80000000u, px);
+                        }
+                    } else {
+                        double col[DC_COLS];
+                        if (part) {
+#pragma unroll
+                            for (uint32_t c = 0; c < DC_COLS; c++) col[c] = wb[c * C];
+                            if (hit) {
+                                uint32_t dw, px; unpack2(col[DC_DEPTH_PX], dw, px);
+                                col[DC_CLOSEST] = (double)t; col[DC_ID] = pack2(oi, prim); col[DC_DEPTH_PX] = pack2(dw | 0x80000000u, px);
+                            }
+                            col[DC_S_NODE] = pack2(s_keep, next);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // every lane holds its path before any slot is overwritten
+                        if (part) {
+                            double* nb = base + ((h_wait + (straggler ? n_fin + lane_rank(sm) : lane_rank(fm))) & (C - 1u));
+#pragma unroll
+                            for (uint32_t c = 0; c < DC_COLS; c++) nb[c * C] = col[c];
+                        }
+                    }
+                    h_wait += n_fin;
+                } else {
+                    if (part && hit) { closest = t; id.obj = oi; id.prim = prim; any_hit = true; }
+                    if (sm != 0ull) {               // own stragglers: their paths go to the ring with the node they stand at
+                        if (straggler) {
+                            defer_store(base + ((tail + lane_rank(sm)) & (C - 1u)), C, ray, closest, id, any_hit, beta, rng, depth_left, path_px, path_s, next);
+                            vacant = true;
+                        }
+                        tail += (uint32_t)__popcll(sm); n_parked += (unsigned long long)__popcll(sm);
+                    }
+                }
+            }
+            DIAG_ADD(3);
+            // ---- lanes without a path take walked ones out of the ring and go on with them behind this object
+            const uint32_t n_done = h_wait - h_done;
+            if (n_done != 0u) {
+                const bool free_lane = vacant || !alive;
+                const unsigned long long want = __ballot(free_lane);
+                if (want != 0ull) {
+                    const uint32_t n_want = (uint32_t)__popcll(want), k = n_want < n_done ? n_want : n_done;
+                    const uint32_t rank = lane_rank(want);
+                    const bool take = free_lane && rank < k;
+                    uint32_t in_px = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the walk's stores
+                    if (take) {
+                        const double* b = base + ((h_done + rank) & (C - 1u));
+                        ray.o = mk<T>((T)b[DC_OX * C], (T)b[DC_OY * C], (T)b[DC_OZ * C]);
+                        ray.d = mk<T>((T)b[DC_DX * C], (T)b[DC_DY * C], (T)b[DC_DZ * C]);
+                        ray.tm = (T)b[DC_TM * C]; closest = (T)b[DC_CLOSEST * C];
+                        beta = mk<T>((T)b[DC_BX * C], (T)b[DC_BY * C], (T)b[DC_BZ * C]);
+                        unpack2(b[DC_RNG01 * C], rng.s0, rng.s1); unpack2(b[DC_RNG23 * C], rng.s2, rng.s3);
+                        unpack2(b[DC_ID * C], id.obj, id.prim);
+                        uint32_t dw; unpack2(b[DC_DEPTH_PX * C], dw, in_px);
+                        depth_left = dw & 0x7FFFFFFFu; any_hit = (dw & 0x80000000u) != 0u;
+                        uint32_t node_unused; unpack2(b[DC_S_NODE * C], path_s, node_unused);
+                    }
+                    h_done += k;
+                    flush_acc(take && acc_px != NONE_PX && acc_px != in_px, acc_px, acc, P.out, lane, n_flush);
+                    if (take) {
+                        if (acc_px != in_px) { acc_px = in_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
+                        path_px = in_px; alive = true; vacant = false; spent = false;
+                    }
+                }
+            }
+            if (lane == ring) { ctl.done = h_done; ctl.wait = h_wait; ctl.tail = tail; }
+            DIAG_ADD(4);
+        }
+        if (vacant) alive = false;                      // the path lives in a ring now
+        if (alive) {
+            bool done = spent;
+            V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
+            if (!spent) {
+                if (!any_hit) {
+                    e = ld3(P.background); done = true;                                     // main.rs:118
+                } else {
+                    Rec<T> rec;
+                    finalize_hit<T, FEATS>(P, ray, closest, id, true, rec);
+                    shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
+                }
+            }
+            if (done) {
+                add_radiance(P, beta * e, acc, n_nonfinite, path_px, path_s);
+                alive = false;
+            }
+        }
+        DIAG_ADD(5);
+    }
+    // ---- the queue is empty: hand in what is left
+    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
+    unsigned long long* const st = stats_row(P.stats);
+    write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
+    if (st && lane == 0) { atomicAdd(&st[9], n_walks); atomicAdd(&st[10], n_walk_lanes); atomicAdd(&st[12], n_parked); }
+#ifdef RT_DIAG
+    if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
+#endif
+}
+
 // ------------------------------------------------------------------ BVH scenes: resumable closest-hit search, persistent traversal
 // With a BVH in the scene the cost of `world.hit` differs wildly between lanes (a ray that misses the root box is done
 // after one node, its neighbour walks a hundred), and in lock-step every lane waits for the slowest one: *measured* VALU
@@ -1540,12 +1823,18 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     //              [WAVES][3][64] f64 per-pixel partial sums (BVH kernels)
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
+    const uint32_t nodes_bytes = P.n_cached * P.lds_node_stride;
     if ((FEATS & F_BVH) && P.n_cached != 0u) {
-        // the top of the BVH, once per workgroup: 16-byte pieces, consecutive threads consecutive pieces; the only barrier of the kernel
+        // the top of the BVH, once per workgroup: 16-byte pieces, consecutive threads consecutive pieces; the only barrier of the kernel.
+        // In LDS a node starts every lds_node_stride bytes (rt_host.cpp: the record plus, possibly, one 16-byte slot of padding, so that
+        // the k-th pieces of different nodes spread over all sixteen 16-byte slots of the bank row instead of four).
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4* src = (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
-        for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
+        constexpr uint32_t PIECES = (uint32_t)sizeof(DBvhNode<T>) / 16u;
+        const u4* src = (const u4*)P.bvh;
+        for (uint32_t i = threadIdx.x; i < P.n_cached * PIECES; i += S::THREADS) {
+            const uint32_t n = i / PIECES, k = i - n * PIECES;
+            *(u4*)(lds_raw + n * P.lds_node_stride + k * 16u) = src[i];
+        }
         __syncthreads();
     }
     const uint32_t QN = P.queue_entries;
@@ -1555,6 +1844,8 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
     double* acc_col = (double*)(lds_raw + nodes_bytes + S::WAVES * (regen_bytes(QN) + P.stack_depth * 256u)) + wave_in_block * (3u * 64u) + lane;   // (ACC_IN_LDS kernels)
     if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col);
+    else if (FEATS & F_DEFER) trace_deferred<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col,
+                                                       P.defer_ring + (size_t)(blockIdx.x * S::WAVES + wave_in_block) * (size_t)(P.defer_rings * P.defer_capacity * DC_COLS));
     else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col);
 }
 
@@ -1608,12 +1899,15 @@ template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<do
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
+    const bool df = (flags & 256u) && (scene_feats & F_BVH) && !nf && !ps;     // RT_DEFER_BVH (reference-order lock-step family only)
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
+        if (df) return f(std::integral_constant<uint32_t, FEATS_MESH | F_DEFER>());
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
+        if (df) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_DEFER>());
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
     }

@@ -34,6 +34,7 @@ struct HostFlat {             // canonical f64 flattening
     std::vector<DLight> lights;
     uint32_t feats = 0;
     uint32_t bvh_depth = 0;
+    uint32_t n_defer_rings = 0;    // bare (non-medium) BVH objects in the world list; each has DObject::pad0 = its index among them
     bool bvh_tame = true;          // all BVH boxes finite, |.| < 1e300 (1e30 matters for the f32 variant: checked there too), min <= max
 };
 
@@ -66,6 +67,7 @@ struct Scene {
     static const int N_SLOTS = 4;
     struct LaunchSlot {
         void* d_queue = nullptr; void* d_stats = nullptr;
+        void* d_defer = nullptr; size_t defer_bytes = 0;       // deferred-BVH-entry kernels: the wavefronts' rings of parked paths
         void* ev_start = nullptr; void* ev_stop = nullptr;
         void* stream = nullptr; bool recorded = false, timed = true; unsigned long long seq = 0;
     };

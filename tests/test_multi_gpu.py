@@ -127,6 +127,31 @@ def test_bench_runs_in_process_without_a_launcher(gpus):
 
 
 @pytest.mark.gpu
+def test_bench_runs_one_process_per_gpu_under_the_launcher():
+    """The driver's documented N > 1 launch — torch.distributed.run, one rank per GPU — here with 2 ranks sharing the one GPU over gloo
+    (RT_BENCH_BACKEND=gloo: RCCL refuses two ranks on one device): rank 0 prints one contract-valid line, `--pipeline auto` times the
+    headline with one and with two frames in flight and reports the better one with both numbers."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    env.pop("RT_MULTI_VIRTUAL_RANKS", None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--also", "C1"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["mode"] == "procs" and "torch.distributed.gather" in d["config"]["parallelism"]
+    assert set(d["pipeline_tried"]) == {"1", "2"} and d["config"]["frames_in_flight"] in (1, 2)
+    assert d["ms_per_step"] == min(v["ms_per_step"] for v in d["pipeline_tried"].values())
+    assert abs(d["value"] - 800 * 800 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
+    assert d["cpu_baseline"] is None and d["roofline"]["traffic"] is None and 0.13 < d["mean_radiance"] < 0.18
+
+
+@pytest.mark.gpu
 def test_render_multi_all_devices(pbe):
     n = R.device_count()
     if n < 2:

@@ -1,5 +1,6 @@
 """A/B timing of kernel variants in ONE process, interleaved rounds (cdna guide §5.4 rule 24).
-usage: python tools/ab.py [--spp 256] [--rounds 5] [--scene cornell] name=path/to/lib.so ...
+usage: python tools/ab.py [--spp 256] [--rounds 5] [--scene cornell] name=path/to/lib.so[@flags[@ENV=V;ENV2=V]] ...
+(per-variant render flags are OR-ed onto --flags; per-variant environment knobs are set around that variant's renders)
 Prints per variant: min / median kernel ms and Msamples/s, and checks variants agree with the first one."""
 import argparse, ctypes as C, os, sys
 import numpy as np
@@ -23,16 +24,24 @@ def build(be):
         return scenes.final_scene(be, *scenes.load_earthmap())
 
 variants = []
+_loaded = {}
 for spec in a.libs:
-    name, path = spec.split('=') if '=' in spec else (os.path.basename(spec), spec)
-    be = _lib.load_path(os.path.abspath(path))
+    name, path = spec.split('=', 1) if '=' in spec else (os.path.basename(spec), spec)
+    parts = path.split('@')
+    path, vflags = parts[0], int(parts[1]) if len(parts) > 1 and parts[1] else 0
+    venv = dict(kv.split('=') for kv in parts[2].split(';')) if len(parts) > 2 and parts[2] else {}
+    path = os.path.abspath(path)
+    be = _loaded.get(path) or _lib.load_path(path)
+    _loaded[path] = be
     b, cam, bg = build(be)
-    variants.append((name, be, b, cam, bg))
+    variants.append((name, be, b, cam, bg, vflags, venv))
 W = H = a.size
 def run(v):
-    name, be, b, cam, bg = v
+    name, be, b, cam, bg, vflags, venv = v
     out = np.zeros((H, W, 3))
-    rc = be.lib.rt_render(b.h, C.byref(cam), (C.c_double * 3)(*bg), W, H, a.spp, a.depth, 0x5EED, a.flags, out.ctypes.data)
+    for k, val in venv.items(): os.environ[k] = val
+    rc = be.lib.rt_render(b.h, C.byref(cam), (C.c_double * 3)(*bg), W, H, a.spp, a.depth, 0x5EED, a.flags | vflags, out.ctypes.data)
+    for k in venv: os.environ.pop(k, None)
     assert rc == 0, be.lib.rt_last_error()
     ms = C.c_float(); be.lib.rt_last_kernel_ms(b.h, C.byref(ms))
     return out, ms.value
