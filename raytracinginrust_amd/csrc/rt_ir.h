@@ -94,7 +94,6 @@ template <typename T> struct KParams {
     const uint8_t* image_bytes;
     uint32_t stack_depth;          // per-lane BVH stack entries staged in LDS: 0 in the reference's traversal order (skip links), the tree depth for near-first
     uint32_t queue_entries;        // camera paths each wave's LDS queue holds (16, 32 or 64; 80 B each)
-    uint32_t lds_node_stride;      // bytes from one cached node to the next in LDS (the record size, or 16 more: see pathtrace_kernel)
     uint32_t n_cached;             // BVH nodes [0, n_cached) are copied into LDS by every workgroup at launch (depth order: the top levels)
     uint32_t bvh_tame;             // every BVH box is finite, below 1e300 in magnitude and has min <= max: rays that are tame too may
                                    // take the NaN-free form of AABB::hit (rt_kernel.hip: box_inside_tame) — same answers
@@ -122,6 +121,8 @@ template <typename T> struct KParams {
     // an object that at least defer_dense lanes of the wave enter is walked on the spot.
     // A walk is suspended once fewer than defer_stop lanes are still in it; the stragglers are walked on with the next batch.
     double* defer_ring; uint32_t defer_capacity, defer_dense, defer_rings, defer_stop;
+    uint32_t lds_node_stride;      // bytes from one cached node to the next in LDS (the record size, or 16 more: see pathtrace_kernel)
+    // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 
 // Wavefront backend (RT_WAVEFRONT): the paths in flight live in two pools of `P` records in HBM, used in turn: a round reads the live

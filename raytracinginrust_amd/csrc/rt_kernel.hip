@@ -1823,7 +1823,7 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     //              [WAVES][3][64] f64 per-pixel partial sums (BVH kernels)
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    const uint32_t nodes_bytes = P.n_cached * P.lds_node_stride;
+    const uint32_t nodes_bytes = (FEATS & F_BVH) ? P.n_cached * P.lds_node_stride : 0u;      // (list-scene kernels stage no nodes)
     if ((FEATS & F_BVH) && P.n_cached != 0u) {
         // the top of the BVH, once per workgroup: 16-byte pieces, consecutive threads consecutive pieces; the only barrier of the kernel.
         // In LDS a node starts every lds_node_stride bytes (rt_host.cpp: the record plus, possibly, one 16-byte slot of padding, so that
