@@ -184,7 +184,9 @@ int rt_render_multi(rt_scene*, const rt_camera*, const double background[3], uin
                     uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out);
 /* The same frame left in device memory: returns once every device's work is enqueued (kernels, gather, un-permute); *d_frame_out (may
  * be NULL) receives a DEVICE pointer on the first selected device to W*H*3 doubles in output order, owned by the scene and valid
- * until the next rt_render_multi* call on it.  One frame is in flight per scene: the next call first waits for the previous one.
+ * until the next rt_render_multi* call on it.  Calls may follow each other without waiting: each device's work is ordered by its own
+ * stream and the host runs at most one frame ahead, so the devices go from frame to frame without a launch gap (a frame of another
+ * shape or device set first waits for the one in flight); timings are kept for the most recent frame.
  * rt_multi_sync waits for the frame; rt_multi_copy_frame waits and copies its first n_doubles doubles to host memory.
  * rt_render_multi = rt_render_multi_device + rt_multi_copy_frame. */
 int rt_render_multi_device(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,

@@ -453,14 +453,19 @@ static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
     l.timed = true;
     return 0;
 }
-// The launch slot for `stream`: the one this stream used last, else an unused one, else the least recently used one once its
-// launch has finished.
+// The launch slot for `stream`.  A stream alternates between (up to) two slots, so that the host can enqueue a frame's kernel while
+// the previous one on that stream still runs — the kernels follow each other on the GPU without a launch gap — and waits only for the
+// launch before that: the slot this stream used least recently if it already has two, else an unused one, else the least recently
+// used one of all once its launch has finished.
 static int acquire_slot(Scene& s, Scene::DeviceCtx& c, hipStream_t stream, Scene::LaunchSlot** out) {
     Scene::LaunchSlot* pick = nullptr;
-    for (Scene::LaunchSlot& l : c.slots) if (l.recorded && l.stream == (void*)stream) { pick = &l; break; }
+    Scene::LaunchSlot* mine_lru = nullptr; int n_mine = 0;
+    for (Scene::LaunchSlot& l : c.slots) if (l.recorded && l.stream == (void*)stream) { n_mine++; if (!mine_lru || l.seq < mine_lru->seq) mine_lru = &l; }
+    if (n_mine >= 2) pick = mine_lru;
     if (!pick) for (Scene::LaunchSlot& l : c.slots) if (!l.recorded) { pick = &l; break; }
+    if (!pick && mine_lru) pick = mine_lru;
     if (!pick) { pick = &c.slots[0]; for (Scene::LaunchSlot& l : c.slots) if (l.seq < pick->seq) pick = &l; }
-    if (settle_slot(s, *pick)) return -1;             // also waits for a launch another stream may still be running in this slot
+    if (settle_slot(s, *pick)) return -1;             // also waits for a launch that may still be running in this slot
     if (!pick->d_queue) HIP_OK(hipMalloc(&pick->d_queue, 64));
     if (!pick->d_stats) HIP_OK(hipMalloc(&pick->d_stats, RT_STATS_BYTES));
     if (!pick->ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); pick->ev_start = e; }

@@ -1482,12 +1482,13 @@ DEV void trace_deferred(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
             const uint32_t n_wait = tail - h_wait;
             const bool walk = !dense && (n_wait >= 64u || (n_wait != 0u && draining));
             if (walk || (dense && n_enter != 0u)) {
-                // BVH::hit (bvh.rs:77-91): for the wave's own entering rays, or for the oldest (up to) 64 parked ones.  The walk is
-                // suspended once fewer than defer_stop lanes are still in it: the stragglers go (back) to the ring with the node they
+                // BVH::hit (bvh.rs:77-91): for the wave's own entering rays, or for the oldest (up to) 64 parked ones.  A walk of parked
+                // paths is suspended once fewer than defer_stop lanes are still in it: the stragglers stay in the ring with the node they
                 // stand at and are walked on together with the next batch — nobody waits for the longest ray of a batch.
                 const uint32_t n_w = n_wait < 64u ? n_wait : 64u;
-                uint32_t stop_below = draining ? 1u : P.defer_stop;
-                if (dense && stop_below > room + 1u) stop_below = room + 1u;          // own stragglers need a slot each
+                // (a walk of the wave's own rays runs to its end: its stragglers would have to wait in the ring for a walk that a wave
+                // whose lanes keep entering together never starts)
+                const uint32_t stop_below = (walk && !draining) ? P.defer_stop : 1u;
                 RayT<T> tr = r; T tcl = closest; bool part = enter; uint32_t node = ob.geom_first, s_keep = 0;
                 double* wb = base + ((h_wait + lane) & (C - 1u));
                 if (walk) {
@@ -1536,16 +1537,7 @@ DEV void trace_deferred(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
                         }
                     }
                     h_wait += n_fin;
-                } else {
-                    if (part && hit) { closest = t; id.obj = oi; id.prim = prim; any_hit = true; }
-                    if (sm != 0ull) {               // own stragglers: their paths go to the ring with the node they stand at
-                        if (straggler) {
-                            defer_store(base + ((tail + lane_rank(sm)) & (C - 1u)), C, ray, closest, id, any_hit, beta, rng, depth_left, path_px, path_s, next);
-                            vacant = true;
-                        }
-                        tail += (uint32_t)__popcll(sm); n_parked += (unsigned long long)__popcll(sm);
-                    }
-                }
+                } else if (part && hit) { closest = t; id.obj = oi; id.prim = prim; any_hit = true; }
             }
             DIAG_ADD(3);
             // ---- lanes without a path take walked ones out of the ring and go on with them behind this object

@@ -306,14 +306,29 @@ int rt_render_multi_device(rt_scene* sc, const rt_camera* cam, const double bg[3
     if (!sc || !cam || !bg) return set_error("null argument");
     if (rt_device_count() <= 0) return set_error("no HIP device: librt_amd has no CPU rendering path");
     Scene& s = sc->s;
-    if (settle(s)) return -1;                       // one frame in flight per scene: the buffers are the scene's
+    // A frame of this scene may still be in flight: it is not waited for.  Every device's work is ordered by its own stream — kernel,
+    // gather, (root) un-permute of frame i, then kernel, gather, ... of frame i + 1 — and so are the buffers they share; the host runs
+    // at most one frame ahead (a launch waits for the launch before the previous one on its stream, rt_host.cpp acquire_slot), so the
+    // devices go from one frame's kernel to the next without a launch gap.  Timings are kept for the most recent frame only.
     if (tile_px == 0) tile_px = 67;                 // the default of dist.py: a prime, so that tile columns drift across rows
+    {   // (a frame of another shape or on other devices may reallocate buffers or communicators: that one waits)
+        unsigned long long virt = 0; if (const char* v = std::getenv("RT_MULTI_VIRTUAL_RANKS")) virt = (unsigned long long)std::strtol(v, nullptr, 10);
+        const unsigned long long sig[4] = {W, H, tile_px, (unsigned long long)device_mask | ((unsigned long long)(flags & (RT_F32 | RT_MULTI_COLLECTIVE)) << 32) | (virt << 48)};
+        bool same = true; for (int k = 0; k < 4; k++) same = same && sig[k] == s.multi_sig[k];
+        if (!same && settle(s)) return -1;
+        for (int k = 0; k < 4; k++) s.multi_sig[k] = sig[k];
+    }
     int cur = 0;
     { const hipError_t e = hipGetDevice(&cur); if (e != hipSuccess) return set_error(hip_msg("hipGetDevice", e)); }
     s.multi_t0 = now_ms();
     std::string err;
+    const std::vector<int> devs_before = s.multi_devs;
     const bool ok = enqueue_frame(sc, cam, bg, W, H, spp, max_depth, seed, flags, device_mask, tile_px, err);
-    if (!ok) drain(s);                              // whatever was launched before the failure finishes before anything is reused
+    if (!ok) {                                      // whatever was launched — of this frame or the one before — finishes before anything is reused
+        drain(s);
+        const std::vector<int> devs_now = s.multi_devs;
+        s.multi_devs = devs_before; drain(s); s.multi_devs = devs_now;
+    }
     s.multi_pending = ok;
     if (ok && d_frame_out) *d_frame_out = s.ctx_for(s.multi_devs[0]).d_frame;
     (void)hipSetDevice(cur);                        // a PyTorch host keeps its current device

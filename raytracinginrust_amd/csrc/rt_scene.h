@@ -95,6 +95,7 @@ struct Scene {
     // state of the rt_render_multi* frame in flight (rt_multi_sync settles it): the devices it runs on, four events on the root
     // device's stream, the host clock at the call's entry; the virtual-rank test hook's tile buffers (all on the root device)
     std::vector<int> multi_devs; bool multi_pending = false; double multi_t0 = 0.0;
+    unsigned long long multi_sig[4] = {0, 0, 0, 0};      // shape of the frame in flight (W, H, tile_px, device mask | flags): a differently shaped next frame waits for it
     void* multi_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int multi_ev_device = -1;
     std::vector<void*> virtual_tiles; size_t virtual_tiles_bytes = 0; int virtual_tiles_device = -1;
     double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
