@@ -52,12 +52,13 @@ def load_path(path: str) -> Backend:
     lib.rt_render_device.argtypes = common + [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.rt_render_multi.restype = C.c_int
     lib.rt_render_multi.argtypes = common + [C.c_uint32, C.c_uint32, C.c_void_p]
-    lib.rt_render_multi_device.restype = C.c_int
-    lib.rt_render_multi_device.argtypes = common + [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
-    lib.rt_multi_sync.restype = C.c_int
-    lib.rt_multi_sync.argtypes = [C.c_void_p]
-    lib.rt_multi_copy_frame.restype = C.c_int
-    lib.rt_multi_copy_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    if hasattr(lib, "rt_render_multi_device"):       # (tools/ab.py also loads builds of earlier rounds)
+        lib.rt_render_multi_device.restype = C.c_int
+        lib.rt_render_multi_device.argtypes = common + [C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        lib.rt_multi_sync.restype = C.c_int
+        lib.rt_multi_sync.argtypes = [C.c_void_p]
+        lib.rt_multi_copy_frame.restype = C.c_int
+        lib.rt_multi_copy_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     lib.rt_last_multi_ms.restype = C.c_int
     lib.rt_last_multi_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.rt_kernel_time_total.restype = C.c_int

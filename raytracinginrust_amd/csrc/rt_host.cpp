@@ -505,19 +505,13 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
 
 // BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
 // queues and stacks; 0 for the list-scene kernels.
-// bytes from one cached BVH node to the next in LDS (see pathtrace_kernel)
-template <typename T> size_t lds_node_stride() {
-    size_t stride = sizeof(DBvhNode<T>);
-    if (const char* v = std::getenv("RT_NODE_LDS_PAD")) { const long n = std::strtol(v, nullptr, 10); if (n == 16 || n == 0) stride = sizeof(DBvhNode<T>) + (size_t)n; }   // A/B runs only
-    return stride;
-}
 template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop, uint32_t stack_depth) {
     if (!g.one_per_cu || f.bvh.empty()) return 0u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     if (lds_total < 65536u) lds_total = 65536u;
-    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, lds_node_stride<T>());
-    if (fixed + lds_node_stride<T>() > lds_total) return 0u;
-    size_t room = (lds_total - fixed) / lds_node_stride<T>();
+    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, sizeof(DBvhNode<T>));
+    if (fixed + sizeof(DBvhNode<T>) > lds_total) return 0u;
+    size_t room = (lds_total - fixed) / sizeof(DBvhNode<T>);
     // RT_NODE_CACHE_MAX (tests, A/B runs): stage at most that many nodes (0 = every node comes from global memory); scheduling only
     if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
     return (uint32_t)std::min(room, f.bvh.size());
@@ -572,7 +566,6 @@ int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const
     size_t room = lds_total > stacks ? (lds_total - stacks) / sizeof(DBvhNode<T>) : 0;
     if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
     P.n_cached = (uint32_t)std::min(room, f.bvh.size());
-    P.lds_node_stride = (uint32_t)sizeof(DBvhNode<T>);
     const size_t shmem = (size_t)P.n_cached * sizeof(DBvhNode<T>) + stacks;
     uint64_t n_alive = 0, next_sample = 0;
     int cur = 0;
@@ -671,8 +664,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         if (n == 16 || n == 32 || n == 64) { shape.queue_entries = (uint32_t)n; P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth); }
     }
     P.queue_entries = shape.queue_entries;
-    P.lds_node_stride = (uint32_t)lds_node_stride<T>();
-    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, lds_node_stride<T>());
+    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel (LDS: " + std::to_string(shmem) + " bytes per workgroup)");
     const uint64_t waves_per_block = shape.threads / 64u;
@@ -794,8 +786,8 @@ int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     int bpc;
     const uint32_t sd = stack_depth_of(s.flat, eff);
-    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), lds_node_stride<float>()));
-    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd), lds_node_stride<double>()));
+    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), sizeof(DBvhNode<float>)));
+    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd), sizeof(DBvhNode<double>)));
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;

@@ -121,7 +121,6 @@ template <typename T> struct KParams {
     // an object that at least defer_dense lanes of the wave enter is walked on the spot.
     // A walk is suspended once fewer than defer_stop lanes are still in it; the stragglers are walked on with the next batch.
     double* defer_ring; uint32_t defer_capacity, defer_dense, defer_rings, defer_stop;
-    uint32_t lds_node_stride;      // bytes from one cached node to the next in LDS (the record size, or 16 more: see pathtrace_kernel)
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 

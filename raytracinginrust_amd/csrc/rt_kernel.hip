@@ -416,7 +416,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 // the ids below n_cached are the top levels of every tree, where most visits go: each workgroup holds them in LDS (one copy per
 // CU: the BVH kernels run one workgroup per CU) and a visit there is four ds_read_b128 instead of four global loads.
 template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t node) {
-    if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * P.lds_node_stride);
+    if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * (uint32_t)sizeof(DBvhNode<T>));
 #ifdef RT_NODE_SOA      // measurement build only: the north_star's field-wise structure-of-arrays node layout
     DBvhNode<T> nd;
     const uint32_t n = P.n_bvh;
@@ -1815,18 +1815,15 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     //              [WAVES][3][64] f64 per-pixel partial sums (BVH kernels)
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    const uint32_t nodes_bytes = (FEATS & F_BVH) ? P.n_cached * P.lds_node_stride : 0u;      // (list-scene kernels stage no nodes)
+    const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
     if ((FEATS & F_BVH) && P.n_cached != 0u) {
         // the top of the BVH, once per workgroup: 16-byte pieces, consecutive threads consecutive pieces; the only barrier of the kernel.
-        // In LDS a node starts every lds_node_stride bytes (rt_host.cpp: the record plus, possibly, one 16-byte slot of padding, so that
-        // the k-th pieces of different nodes spread over all sixteen 16-byte slots of the bank row instead of four).
+        // (Round 3: one 16-byte slot of padding per node, so that the k-th pieces of different nodes spread over all sixteen slots of the
+        // LDS bank row instead of four, was measured and is not faster — random spheres -1.4 %, final scene -1.5 %, teapot room -6 %, whose
+        // tree then no longer fits: bank conflicts are not what a step waits for.)
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        constexpr uint32_t PIECES = (uint32_t)sizeof(DBvhNode<T>) / 16u;
-        const u4* src = (const u4*)P.bvh;
-        for (uint32_t i = threadIdx.x; i < P.n_cached * PIECES; i += S::THREADS) {
-            const uint32_t n = i / PIECES, k = i - n * PIECES;
-            *(u4*)(lds_raw + n * P.lds_node_stride + k * 16u) = src[i];
-        }
+        const u4* src = (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
+        for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
         __syncthreads();
     }
     const uint32_t QN = P.queue_entries;
