@@ -1,0 +1,12 @@
+#!/bin/bash
+# Copies what tools/profile_all.sh left under gpurun_out/ (scratch) into profiles/ (tracked) under the names the README documents.
+# usage: tools/collect_profiles.sh <tag> C1 C2 ...
+set -e
+cd "$(dirname "$0")/.."
+TAG=$1; shift
+for W in "$@"; do
+  tail -1 gpurun_out/prof_${TAG}_$W/bench.json > profiles/${TAG}_bench_$W.json
+  cp gpurun_out/prof_${TAG}_$W/trace/*/*_kernel_stats.csv profiles/${TAG}_bench_${W}_kernel_stats.csv
+  cp gpurun_out/pmc_${TAG}_$W/summary.csv profiles/${TAG}_bench_${W}_pmc_summary.csv
+done
+ls -la profiles/${TAG}_*
