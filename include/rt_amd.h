@@ -242,6 +242,14 @@ int rt_debug_bvh_links(rt_scene*, uint32_t* out, uint32_t max_nodes, uint32_t* r
  * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
  * traversal uses for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300).  Non-zero on a HIP error. */
 int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out);
+/* Debugging aid for parity work: the hits of ONE camera path, level by level.  rt_debug_trace_path chooses the path (local pixel index =
+ * output-order pixel for an unsharded render, sample index; -1 switches it off); the following renders record, per level of ray_color
+ * that found a hit, 16 doubles at out[16 * level]: t, position[3], normal[3], front_face, object, primitive kind, primitive index,
+ * material, incoming direction[3], 1.0 (a level without a hit stays all zero); rt_debug_get_trace fetches n_levels of them.  Only the
+ * lock-step kernels of a -DRT_TRACE_PATH build of the library write the record (tools/mkab.sh trace "-DRT_TRACE_PATH" "-DRT_TRACE_PATH";
+ * the shipped build leaves it zero) — tools/fuzz_probe.py compares it with the oracle's orc_trace_path. */
+int rt_debug_trace_path(rt_scene*, long long local_pixel, long long sample);
+int rt_debug_get_trace(rt_scene*, double* out, uint32_t n_levels);
 /* Debug/parity aid: like rt_render but also returns every sample's radiance (W*H*spp*3 doubles). */
 int rt_render_samples(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
                       uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,

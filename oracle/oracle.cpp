@@ -115,6 +115,8 @@ typedef Rng SamplerRng;
 struct Sampler {
     SamplerRng rng;
     Counters c;
+    // debugging aid (orc_trace_path): when set, every level of ray_color appends {t, position, normal, front_face, incoming direction, 0} of its hit (t = inf: none): 12 doubles
+    double* trace = nullptr; int trace_max = 0, trace_n = 0;
 };
 
 // Rust float semantics helpers
@@ -1079,7 +1081,14 @@ static Color ray_color(const Ray& ray, const Color& background, const Hittable* 
     if (depth <= 0) return Color(0.0, 0.0, 0.0);                                                     // main.rs:42-45
     ORC_COUNT(s.c.world_hits++);
     HitRecord rec;
-    if (world->hit(ray, 0.00001, F64_INF, s, rec)) {                                                 // main.rs:48
+    const bool any_hit = world->hit(ray, 0.00001, F64_INF, s, rec);                                  // main.rs:48
+    if (s.trace && s.trace_n < s.trace_max) {
+        double* o = s.trace + 12 * s.trace_n++;
+        o[0] = any_hit ? rec.t : F64_INF;
+        for (int k = 0; k < 3; k++) { o[1 + k] = any_hit ? rec.position[k] : 0.0; o[4 + k] = any_hit ? rec.normal[k] : 0.0; o[8 + k] = ray.direction()[k]; }
+        o[7] = (any_hit && rec.front_face) ? 1.0 : 0.0; o[11] = 0.0;
+    }
+    if (any_hit) {
         ORC_COUNT(s.c.shades++);
         Color emitted = rec.material->emitted(rec, s);                                               // main.rs:62
         ScatterRecord srec;
@@ -1329,6 +1338,23 @@ int orc_render(void* s, const orc_camera* camp, const double* bg, uint32_t W, ui
         std::memcpy(counters, &tot.samples, sizeof(uint64_t) * Counters::N);
     }
     return 0;
+}
+// Debugging aid: the hits of ONE camera path, level by level — out[12 * level ..] = {t (inf: no hit), position, normal, front_face, incoming direction, 0}.
+// Returns the number of levels recorded.  (tools/fuzz_probe.py compares it with the kernel's rt_debug_get_trace.)
+int orc_trace_path(void* s, const orc_camera* camp, const double* bg, uint32_t W, uint32_t H, uint32_t i, uint32_t j, uint32_t s_idx, uint64_t depth,
+                   uint64_t seed, double* out, int max_levels) {
+    if (!SC->world) return -1;
+    Camera cam = make_camera(camp);
+    Sampler smp; smp.trace = out; smp.trace_max = max_levels;
+    uint32_t pixel = (H - 1 - j) * W + i;
+    smp.rng = Rng::for_path(seed, pixel, s_idx);
+    double random_u = smp.rng.u01();
+    double random_v = smp.rng.u01();
+    double u = ((double)i + random_u) / (double)(W - 1);
+    double v = ((double)j + random_v) / (double)(H - 1);
+    Ray r = cam.get_ray(u, v, smp);
+    (void)ray_color(r, V(bg), SC->world, &SC->lights, depth, smp);
+    return smp.trace_n;
 }
 int orc_counters_n() { return Counters::N; }
 // f64 operations executed by the renders since the last call, by kind (oracle/orc_opcount.h Kind order: add/sub, mul, div, sqrt,

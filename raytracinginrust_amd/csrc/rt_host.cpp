@@ -62,6 +62,7 @@ void rt_scene_destroy(rt_scene* sc) {
     if (!sc) return;
     int cur = 0; (void)hipGetDevice(&cur);
     rt::multi_release(sc->s);
+    if (sc->s.d_trace) { (void)hipSetDevice(sc->s.trace_device); (void)hipFree(sc->s.d_trace); sc->s.d_trace = nullptr; (void)hipSetDevice(cur); }
     for (Scene::DeviceCtx* c : sc->s.ctxs) {
         (void)hipSetDevice(c->device);
         free_device_scene(c->dev64);
@@ -711,6 +712,15 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         }
         P.defer_ring = (double*)slot->d_defer;
     }
+    P.trace_out = nullptr; P.trace_px = 0u; P.trace_s = 0u;
+    if (s.trace_px >= 0) {                          // debugging aid: 16 doubles per level of one path (written by -DRT_TRACE_PATH builds only)
+        const size_t bytes = ((size_t)max_depth + 1u) * 16u * sizeof(double);
+        if (s.d_trace) { (void)hipFree(s.d_trace); s.d_trace = nullptr; }
+        HIP_OK(hipMalloc(&s.d_trace, bytes));
+        HIP_OK(hipMemsetAsync(s.d_trace, 0, bytes, stream));
+        s.trace_device = c.device;
+        P.trace_out = (double*)s.d_trace; P.trace_px = (uint32_t)s.trace_px; P.trace_s = (uint32_t)s.trace_s;
+    }
     HIP_OK(hipMemsetAsync(slot->d_queue, 0, 64, stream));
     HIP_OK(hipMemsetAsync(slot->d_stats, 0, RT_STATS_BYTES, stream));
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)n_local_px * 3 * sizeof(double), stream));
@@ -879,6 +889,20 @@ int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[8]) {
     if (read_stats(sc, h)) return -1;
     for (int k = 0; k < 6; k++) out[k] = h[3 + k];
     out[6] = h[14]; out[7] = h[15];
+    return 0;
+}
+
+// Debugging aid (see include/rt_amd.h): choose the path whose hits the next renders record / fetch the record
+int rt_debug_trace_path(rt_scene* sc, long long local_pixel, long long sample) {
+    if (!sc) return set_err("null argument");
+    sc->s.trace_px = local_pixel; sc->s.trace_s = sample;
+    return 0;
+}
+int rt_debug_get_trace(rt_scene* sc, double* out, uint32_t n_levels) {
+    if (!sc || !out) return set_err("null argument");
+    if (!sc->s.d_trace) return set_err("no path has been traced (rt_debug_trace_path, then a render)");
+    HIP_OK(hipDeviceSynchronize());
+    HIP_OK(hipMemcpy(out, sc->s.d_trace, (size_t)n_levels * 16u * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 

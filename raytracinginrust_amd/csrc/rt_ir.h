@@ -121,6 +121,8 @@ template <typename T> struct KParams {
     // an object that at least defer_dense lanes of the wave enter is walked on the spot.
     // A walk is suspended once fewer than defer_stop lanes are still in it; the stragglers are walked on with the next batch.
     double* defer_ring; uint32_t defer_capacity, defer_dense, defer_rings, defer_stop;
+    // debugging aid (-DRT_TRACE_PATH builds, rt_debug_trace_path): the path (trace_px, trace_s) writes 16 doubles per level to trace_out
+    double* trace_out; uint32_t trace_px, trace_s;
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 

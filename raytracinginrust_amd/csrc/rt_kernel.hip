@@ -1341,6 +1341,15 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
                         rec.t = col[6 * 64]; rec.u = col[7 * 64]; rec.v = col[8 * 64]; rec.front = cu[0] != 0u; rec.mat = cu[64];
                     }
 #endif
+#ifdef RT_TRACE_PATH    // debugging build only (tools/fuzz_probe.py): the hits of one path, level by level, for comparison with the oracle's orc_trace_path
+                    if (P.trace_out && path_px == P.trace_px && path_s == P.trace_s && depth_left <= P.max_depth) {
+                        double* o = P.trace_out + 16u * (P.max_depth - depth_left);
+                        o[0] = (double)rec.t; o[1] = (double)rec.p.x; o[2] = (double)rec.p.y; o[3] = (double)rec.p.z;
+                        o[4] = (double)rec.n.x; o[5] = (double)rec.n.y; o[6] = (double)rec.n.z; o[7] = rec.front ? 1.0 : 0.0;
+                        o[8] = (double)id.obj; o[9] = (double)(id.prim >> 28); o[10] = (double)(id.prim & 0x0FFFFFFFu); o[11] = (double)rec.mat;
+                        o[12] = (double)ray.d.x; o[13] = (double)ray.d.y; o[14] = (double)ray.d.z; o[15] = 1.0;
+                    }
+#endif
                     shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
                 }
             }

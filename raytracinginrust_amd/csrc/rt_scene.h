@@ -100,6 +100,9 @@ struct Scene {
     std::vector<void*> virtual_tiles; size_t virtual_tiles_bytes = 0; int virtual_tiles_device = -1;
     double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
 
+    // debugging aid (rt_debug_trace_path; -DRT_TRACE_PATH builds of the kernels): the path whose hits are recorded, and the device buffer
+    long long trace_px = -1, trace_s = -1; void* d_trace = nullptr; int trace_device = -1;
+
     void invalidate() { flat_valid = false; }
     DeviceCtx& ctx_for(int device) {
         for (DeviceCtx* c : ctxs) if (c->device == device) return *c;
