@@ -181,6 +181,18 @@ def kernel_name_of(w, f32):
     return f"rt::pathtrace_kernel<{t}, FEATS>, FEATS = {feats}"
 
 
+def resolve_mode(mode, gpus, env_world):
+    """How `python bench.py --gpus N` runs: returns (in-process?, number of GPUs).  Under a launcher (WORLD_SIZE > 1) it is one process
+    per GPU and the launcher's world size is the number of GPUs; without one, N > 1 makes this one process drive the N GPUs through
+    rt_render_multi_device — never an error, never a re-launch (a driver that runs `python bench.py --gpus 8` bare gets a line).  Only an
+    explicit `--mode procs` without a launcher is refused."""
+    if mode == "procs" and env_world == 1 and gpus > 1:
+        raise ValueError("bench.py --mode procs --gpus N with N > 1 must be launched with torch.distributed.run --nproc-per-node N "
+                         "(without a launcher, --mode inproc drives the N GPUs from this one process)")
+    inproc = gpus > 1 and env_world == 1 and mode in ("auto", "inproc")
+    return inproc, (gpus if inproc else env_world)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,12 +223,10 @@ def main():
     env_world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.mode == "procs" and env_world == 1 and args.gpus > 1:
-        sys.exit("bench.py --mode procs --gpus N with N > 1 must be launched with torch.distributed.run --nproc-per-node N "
-                 "(without a launcher, --mode inproc drives the N GPUs from this one process)")
-    inproc = args.gpus > 1 and env_world == 1 and args.mode in ("auto", "inproc")
-    if not inproc:
-        args.gpus = env_world                   # under a launcher the launcher's world size is the number of GPUs
+    try:
+        inproc, args.gpus = resolve_mode(args.mode, args.gpus, env_world)
+    except ValueError as e:
+        sys.exit(str(e))
     world = 1 if inproc else env_world          # ranks of the process group (the in-process mode has none)
     n_gpus = args.gpus
     if not torch.cuda.is_available():

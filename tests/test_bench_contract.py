@@ -82,3 +82,23 @@ def test_bench_line_times_the_other_configs():
     assert "reference_shaped" in c and c["reference_shaped"]["value"] > 0 and "flags" in c and "compiler" in c
     r = d["roofline"]
     assert (r["bytes_per_sample"] if r["bound"] == "hbm" else r["model_hbm"]["bytes_per_sample"]) == workloads.BYTES_PER_SAMPLE["C2"]
+
+
+def test_bench_never_refuses_a_bare_gpus_flag():
+    """`python bench.py --gpus N` must produce a line however the driver launches it: bare (this process drives the N GPUs), or under
+    torch.distributed.run (one process per GPU; the launcher's world size wins over a stale --gpus)."""
+    import importlib.util
+    import pytest
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for n in (2, 4, 8):
+        assert bench.resolve_mode("auto", n, 1) == (True, n)            # no launcher: in-process, rt_render_multi_device
+        assert bench.resolve_mode("inproc", n, 1) == (True, n)
+        assert bench.resolve_mode("auto", n, n) == (False, n)           # torch.distributed.run: one process per GPU
+        assert bench.resolve_mode("procs", n, n) == (False, n)
+        assert bench.resolve_mode("auto", 1, n) == (False, n)           # the launcher's world size is the number of GPUs
+        with pytest.raises(ValueError, match="torch.distributed.run"):
+            bench.resolve_mode("procs", n, 1)
+    assert bench.resolve_mode("auto", 1, 1) == (False, 1)
+    assert bench.resolve_mode("inproc", 1, 1) == (False, 1)
