@@ -497,9 +497,69 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     return any;
 }
 
+// The same search with SPECULATIVE box steps (reference order, tame rays): a lane that has reached a leaf does not wait for the leaf step
+// — it walks on along the leaf's skip link with its closest hit as it is, and waits only once it holds a second leaf.  The leaf step
+// tests one pending leaf per lane; a leaf that was reached past an untested one is first re-tested against its own box with the closest
+// hit as it is NOW, and dropped if that fails.  Same result as BVH::hit (bvh.rs:77-91), by containment: a child's box lies inside its
+// parent's (the parent's bounds are the min / max of the children's, aabb.rs:40-51), subtraction, multiplication by 1/d and min / max are
+// monotonic, so a child's slab interval lies inside every ancestor's — exactly, in floating point.  Hence (1) if the leaf's box passes
+// with the current closest hit, every ancestor on the way to it passes too: the recursion would have reached the leaf and tested it with
+// this very t_max; (2) if it fails, the recursion would have failed at the leaf's box or earlier and never tested the leaf; (3) box
+// tests made with the stale (larger) closest hit can only pass where the recursion's would fail, never the reverse, so no leaf the
+// recursion tests is missed, and the extra nodes walked below a box the recursion would have culled all fail their own re-test.
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 0
+#endif
+#ifndef RT_SPEC_NUM
+#define RT_SPEC_NUM 3u
+#define RT_SPEC_DEN 8u
+#endif
+template <typename T, uint32_t FEATS>
+DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+    const V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
+    T closest = t_max;
+    bool any = false;
+    const uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t node = root, p1 = NONE, p2 = NONE;        // where the walk stands; the pending leaves (node ids), oldest first
+    bool spec1 = false;                                // p1 was reached past an untested leaf: its box is re-tested before its primitives
+    const bool tame = P.bvh_tame != 0u && __ballot(!ray_is_tame(ray.o, inv)) == 0ull;   // wave-uniform; untamed rays (NaNs possible) do not speculate
+    for (;;) {
+        for (;;) {
+            const bool can_box = node != NONE && (tame ? p2 == NONE : p1 == NONE);
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(can_box)), n_leaf = (uint32_t)__popcll(__ballot(p1 != NONE)),
+                           n_act = (uint32_t)__popcll(__ballot(node != NONE || p1 != NONE));
+            if (n_box == 0u || n_leaf * RT_SPEC_DEN >= n_act * RT_SPEC_NUM) break;
+            auto box_step = [&]() {
+                const DBvhNode<T> nd = fetch_node(P, node);
+                const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, closest) : box_inside_exact(nd, ray.o, inv, t_min, closest);
+                const bool leaf = (nd.a & BVH_LEAF) != 0u;
+                if (inside && leaf) { if (p1 == NONE) p1 = node; else p2 = node; }
+                node = (inside && !leaf) ? nd.c : nd.skip;
+            };
+            if (can_box) box_step();
+#pragma unroll
+            for (int k = 1; k < RT_BOX_STEPS; k++) if (node != NONE && (tame ? p2 == NONE : p1 == NONE)) box_step();
+        }
+        if (p1 != NONE) {
+            const DBvhNode<T> lf = fetch_node(P, p1);
+            bool go = true;
+            if (spec1) go = box_inside_tame(lf, ray.o, inv, t_min, closest);           // (speculation only happens on tame rays)
+            T t; uint32_t prim;
+            if (go && range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
+            p1 = p2; spec1 = p2 != NONE; p2 = NONE;
+        }
+        if (__ballot(node != NONE || p1 != NONE) == 0ull) break;
+    }
+    t_out = closest;
+    return any;
+}
+
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack,
                  uint32_t stop_below = 1u, uint32_t* next_node = nullptr) {
+#if RT_SPECULATE
+    if (!(FEATS & F_NEAR_FIRST) && next_node == nullptr) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
+#endif
     return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack, stop_below, next_node);
 }
 
