@@ -61,6 +61,10 @@ enum {
                               wait at such an object the wavefront walks it for all of them at once.  Chosen automatically where it
                               pays; this flag forces it on ...                                                     */
     RT_NO_DEFER_BVH = 512, /* ... and this one off                                                                            */
+    RT_SPECULATE_BVH = 1024, /* scheduling only, same samples (lock-step BVH kernel): a lane that has reached a leaf walks on while it waits for the
+                              leaf step (rt_kernel.hip: bvh_hit_spec).  Chosen automatically for scenes whose world is one BVH (every ray
+                              enters it); this flag forces it on ...                                                          */
+    RT_NO_SPECULATE_BVH = 2048, /* ... and this one off                                                                        */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
                               old `scatter` (src/mat.rs:417-421) instead of absorbing — the look of img/volume.png       */
 };

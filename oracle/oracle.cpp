@@ -119,6 +119,13 @@ struct Sampler {
     double* trace = nullptr; int trace_max = 0, trace_n = 0;
 };
 
+// sin and cos of one argument as ONE libm sincos call (see Rotate::new)
+#ifdef ORC_COUNT_OPS
+static inline void orc_sincos(double x, double& s, double& c) { orc_ops::tick(orc_ops::SIN); orc_ops::tick(orc_ops::COS); orc_ops::raw_f64 rs, rc; ::sincos(x.v, &rs, &rc); s = double(rs); c = double(rc); }
+#else
+static inline void orc_sincos(double x, double& s, double& c) { ::sincos(x, &s, &c); }
+#endif
+
 // Rust float semantics helpers
 static inline double f_max(double a, double b) { return std::fmax(a, b); }   // f64::max ignores NaN
 static inline double f_min(double a, double b) { return std::fmin(a, b); }
@@ -921,8 +928,10 @@ struct Rotate : Hittable {
     int axis; double sin_theta, cos_theta; const Hittable* hittable; bool has_box; AABB aabb;
     Rotate(int ax, const Hittable* h, double angle) : axis(ax), hittable(h) {                         // rotate.rs:32-74
         double radiants = (PI / 180.0) * angle;
-        sin_theta = std::sin(radiants);
-        cos_theta = std::cos(radiants);
+        // rotate.rs:35-36 `radians.sin()` / `radians.cos()`: one operand, one block — LLVM emits ONE sincos libcall for the pair on
+        // x86-64 linux-gnu (and g++ -O3 does the same to the two calls below it used to be); glibc's sincos differs from sin() / cos() in the
+        // last ulp for 0.13 % of arguments, so the choice is made explicit here and in the product's flattener (csrc/rt_flatten.cpp).
+        orc_sincos(radiants, sin_theta, cos_theta);
         AABB b;
         has_box = h->bounding_box(0.0, 1.0, b);
         if (has_box) {

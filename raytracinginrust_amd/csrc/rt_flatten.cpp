@@ -300,7 +300,12 @@ struct Flattener {
             else {
                 op.kind = OP_ROTATE; op.axis = (uint32_t)h.plane_or_axis;
                 double radiants = (3.14159265358979323846264338327950288 / 180.0) * h.v[0];    // rotate.rs:34-36
-                op.x = std::sin(radiants); op.y = std::cos(radiants);
+                // `radians.sin()` and `radians.cos()` of one operand in one block: LLVM's legaliser turns the pair into ONE sincos libcall
+                // where the C library has it (x86-64 linux-gnu), and glibc's sincos differs from its sin() / cos() in the last ulp for
+                // 0.13 % of arguments (*measured*, glibc 2.35: 2594 of 2e6) — enough to flip which of two coincident triangles behind such
+                // a Rotate wins an exact tie (found by the round-3 fuzz sweep).  So: sincos, explicitly, here and in the oracle.
+                double sn, cs; ::sincos(radiants, &sn, &cs);
+                op.x = sn; op.y = cs;
             }
             return emit(h.child, c2, medium);
         }

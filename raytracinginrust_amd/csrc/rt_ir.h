@@ -44,7 +44,8 @@ enum Feat : uint32_t {
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
     F_DEFER = 1u << 9,      // not a scene feature: lock-step loop with deferred entry into sparsely entered BVH objects (RT_DEFER_BVH)
-    F_NO_PLAIN_BVH = 1u << 10   // (inside the F_DEFER kernels) object_hit without the arm for bare BVH objects: the caller walks those
+    F_NO_PLAIN_BVH = 1u << 10,  // (inside the F_DEFER kernels) object_hit without the arm for bare BVH objects: the caller walks those
+    F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
 static const uint32_t RT_MAX_DEFER_RINGS = 4u;     // deferrable BVH objects per scene (one ring of parked paths per object and wavefront)
 

@@ -507,11 +507,15 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
 // this very t_max; (2) if it fails, the recursion would have failed at the leaf's box or earlier and never tested the leaf; (3) box
 // tests made with the stale (larger) closest hit can only pass where the recursion's would fail, never the reverse, so no leaf the
 // recursion tests is missed, and the extra nodes walked below a box the recursion would have culled all fail their own re-test.
+// Where it pays (*measured*, round 3; leaf step once 3/8 ... 8/8 of the active lanes hold a leaf): random spheres — every lane enters the
+// tree — +1.6 / +2.1 / +2.6 (5/8) / +2.3 / -5 %; final scene -3 %, teapot room in lock-step -3 % (few lanes enter: the waiting it removes is
+// a fifth of the box steps' lane-slots and half of what it walks instead is wasted).  So it has its own instantiation (F_SPEC), chosen
+// by the host for scenes whose world is one BVH; -DRT_SPECULATE=1 turns it on in every lock-step BVH kernel (measurement builds).
 #ifndef RT_SPECULATE
 #define RT_SPECULATE 0
 #endif
 #ifndef RT_SPEC_NUM
-#define RT_SPEC_NUM 3u
+#define RT_SPEC_NUM 5u
 #define RT_SPEC_DEN 8u
 #endif
 template <typename T, uint32_t FEATS>
@@ -557,9 +561,7 @@ DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack,
                  uint32_t stop_below = 1u, uint32_t* next_node = nullptr) {
-#if RT_SPECULATE
-    if (!(FEATS & F_NEAR_FIRST) && next_node == nullptr) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
-#endif
+    if ((RT_SPECULATE || (FEATS & F_SPEC)) && !(FEATS & F_NEAR_FIRST) && next_node == nullptr) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
     return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack, stop_below, next_node);
 }
 
@@ -1965,6 +1967,7 @@ template <typename T, typename F, typename L> static auto dispatch(uint32_t scen
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
+        if ((flags & 1024u) && !nf && !ps && !df) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
         if (df) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_DEFER>());
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());

@@ -799,3 +799,56 @@ def test_deferred_bvh_entry_is_scheduling_only(name, pbe, obe, orc_mod, earth, m
         c = D.TileRenderer(b, cam, bg, W, H, spp, depth, flags=R.RT_DEFER_BVH, tile_px=64, rank=rank, world=3).render_local().clone()
         torch.cuda.synchronize()
         assert torch.allclose(a, c, rtol=1e-12, atol=1e-12 * spp, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["random", "final", "mesh0", "teapot"])
+def test_speculative_box_steps_are_scheduling_only(name, pbe, obe, orc_mod, earth):
+    """RT_SPECULATE_BVH: in the lock-step BVH walk a lane that has reached a leaf walks on along the leaf's skip link while it waits for
+    the leaf step, holds at most two leaves, and a leaf reached past an untested one is re-tested against its own box with the closest hit
+    as it is when its turn comes (rt_kernel.hip: bvh_hit_spec; exact by containment of a child's slab interval in its ancestors').
+    Chosen automatically when the world is ONE BVH (random spheres); forced on here for the others.  Every sample is bit-identical to the
+    plain walk and matches the oracle."""
+    mk = (lambda be: _mesh_room(be, 0)) if name == "mesh0" else (lambda be: build_scene(name, be, earth))
+    b, cam, bg = mk(pbe)
+    W, H, spp, depth = 96, 54, 8, 30
+    _, plain = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH | R.RT_NO_DEFER_BVH, want_samples=True)
+    _, spec = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_SPECULATE_BVH, want_samples=True)
+    assert np.array_equal(plain.view(np.uint64), spec.view(np.uint64))
+    _, auto = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    assert np.array_equal(plain.view(np.uint64), auto.view(np.uint64))
+    ob, ocam, obg = mk(obe)
+    _, ref = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
+    n_div, _, _ = _compare_samples(spec, ref)
+    assert n_div <= MAX_DIVERGED
+
+
+def test_rotation_by_an_angle_whose_sincos_differs_from_sin_and_cos(pbe, obe, orc_mod):
+    """Found by the round-3 fuzz sweep (seed 38793: 35 diverged samples in one scene).  glibc's sincos() differs from its sin() / cos() in
+    the last ulp for 0.13 % of arguments — one of them (pi/180) * -73.5789378649801 — and LLVM (hence rustc) turns `radians.sin()` /
+    `radians.cos()` of Rotate::new (rotate.rs:35-36) into one sincos call, as g++ -O3 does in the oracle, while the product's flattener
+    (clang) made two calls: the rotation matrices differed by an ulp, and behind such a Rotate two coincident triangles (a Mesh that names
+    one triangle twice with its vertices rotated: their t differ in the last ulp) swapped which one wins.  Both sides call sincos explicitly
+    now; this is that scene's mesh: every sample must be bit-comparable again."""
+    def build(be):
+        b = SceneBuilder(be)
+        glow = b.DiffuseLight(b.ConstantTexture((4.0, 4.0, 4.0)))
+        grey = b.Lambertian(b.ConstantTexture((0.6, 0.5, 0.4)))
+        verts = [(24.623369398270484, 39.450005170621395, 9.599462891678257), (17.623561837599567, -38.37418967943361, 12.201314173323262),
+                 (39.8930862122764, -18.061201982550102, 26.50247531565779), (39.724616296882246, 23.61365762872029, 23.618362277751473),
+                 (19.023481207843886, -3.657442987881069, -29.076281302200968)]
+        mesh = b.Mesh(verts, [3, 2, 1, 1, 3, 2, 2, 3, 4], grey)
+        h = b.Rotate(Axis.Y, b.Rotate(Axis.Y, b.Rotate(Axis.Y, mesh, 9.042999908477967), 27.074643535137966), -73.5789378649801)
+        world = b.HittableList()
+        world.push(h)
+        lamp = b.AARect(Plane.XZ, -60.0, 60.0, -60.0, 60.0, 90.0, glow)
+        world.push(lamp)
+        b.set_scene(world, [lamp])
+        return b, Camera((24.0, 13.0, -170.0), (17.0, 16.0, 42.0), (0.0, 1.0, 0.0), 25.0, 1.0, 0.0, 10.0, 0.0, 1.0), (0.1, 0.1, 0.2)
+    pb, pcam, pbg = build(pbe)
+    ob, ocam, obg = build(obe)
+    W, H, spp, depth = 64, 64, 8, 10
+    _, gs = R.render(pb, pcam, pbg, W, H, spp, depth, want_samples=True)
+    _, rs = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
+    n_bad, max_d, _ = _compare_samples(gs, rs)
+    assert (rs.sum(axis=-1) > 0).mean() > 0.05           # the mesh is in view and lit
+    assert n_bad == 0, f"{n_bad} samples diverged (max |d| of the rest {max_d:.2e})"
