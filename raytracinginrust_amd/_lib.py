@@ -34,6 +34,10 @@ def load_path(path: str) -> Backend:
         raise LibraryMissing(
             f"{path} is missing: build it with `make -C raytracinginrust_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
+    try:                # PyTorch first, when it is there: it brings its own copy of the HIP runtime, and a process in which this library's copy was
+        import torch    # loaded before it leaves torch without a device ("No HIP GPUs are available") — dist.py and bench.py need both
+    except ImportError: # noqa: F401
+        pass
     lib = C.CDLL(path)
     be = Backend(lib, "rt_")
     cam_p = C.POINTER(CameraParams)

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                    # before librt_amd.so is loaded by any fixture: PyTorch brings its own copy of the HIP runtime, and a process in which the
+    import torch        # library's copy came first leaves torch without a device ("No HIP GPUs are available"); bench.py keeps the same order
+except ImportError:     # noqa: F401
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

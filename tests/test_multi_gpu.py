@@ -152,6 +152,33 @@ def test_bench_runs_one_process_per_gpu_under_the_launcher():
 
 
 @pytest.mark.gpu
+def test_render_multi_random_frame_shapes_and_tile_sizes(pbe, monkeypatch):
+    """The N-rank decomposition over random frame shapes, tile sizes (also larger than a row, larger than the frame, 1) and rank counts:
+    rt_render_multi (virtual ranks on the one device, the real un-permute kernel) == rt_render, and so is the one-process-per-GPU
+    decomposition (rt_render_device per rank + dist.assemble) for the same shape."""
+    import torch
+    from raytracinginrust_amd import dist as D
+    b, cam, bg = scenes.cornell_box(pbe, aspect_ratio=1.3)
+    rs = np.random.RandomState(7)
+    for case in range(24):
+        W, H = int(rs.randint(2, 97)), int(rs.randint(2, 61))
+        ranks = int(rs.choice([2, 3, 5, 7, 8, 16]))
+        tile = int(rs.choice([1, 2, 7, 64, 67, 100, W, W + 1, W * H, W * H + 5]))
+        spp = int(rs.randint(1, 5))
+        ref = R.render(b, cam, bg, W, H, spp, 12)
+        monkeypatch.setenv("RT_MULTI_VIRTUAL_RANKS", str(ranks))
+        got = R.render_multi(b, cam, bg, W, H, spp, 12, device_mask=1, tile_px=tile)
+        monkeypatch.delenv("RT_MULTI_VIRTUAL_RANKS")
+        assert np.all(np.abs(got - ref) <= 1e-12 * (spp + np.abs(ref))), (W, H, ranks, tile, spp)
+        parts = []
+        for rank in range(ranks):
+            parts.append(D.TileRenderer(b, cam, bg, W, H, spp, 12, tile_px=tile, rank=rank, world=ranks).render_local().clone())
+        torch.cuda.synchronize()
+        frame = D.assemble(torch.stack(parts), W, H, tile).cpu().numpy()
+        assert np.all(np.abs(frame - ref) <= 1e-12 * (spp + np.abs(ref))), (W, H, ranks, tile, spp)
+
+
+@pytest.mark.gpu
 def test_render_multi_all_devices(pbe):
     n = R.device_count()
     if n < 2:
