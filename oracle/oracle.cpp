@@ -441,8 +441,10 @@ static Vec3 random_cosine_direction(Sampler& s) {                      // pdf.rs
     double r2 = s.rng.u01();
     double z = std::sqrt(1.0 - r2);
     double phi = 2.0 * PI * r1;
-    double x = std::cos(phi) * std::sqrt(r2);
-    double y = std::sin(phi) * std::sqrt(r2);
+    double sin_phi, cos_phi;
+    orc_sincos(phi, sin_phi, cos_phi);       // pdf.rs:14-15 `phi.cos()` / `phi.sin()`: one operand, one block -> one sincos libcall (see Rotate::new)
+    double x = cos_phi * std::sqrt(r2);
+    double y = sin_phi * std::sqrt(r2);
     return Vec3(x, y, z);
 }
 // mat.rs:10-52 helpers of the principled ("Disney") material
@@ -711,8 +713,10 @@ static Vec3 random_to_sphere(double radius, double distance_squared, Sampler& s)
     double r2 = s.rng.u01();
     double z = 1.0 + r2 * (std::sqrt(1.0 - radius * radius / distance_squared) - 1.0);
     double phi = 2.0 * PI * r1;
-    double x = std::cos(phi) * std::sqrt(1.0 - z * z);
-    double y = std::sin(phi) * std::sqrt(1.0 - z * z);
+    double sin_phi, cos_phi;
+    orc_sincos(phi, sin_phi, cos_phi);       // sphere.rs:33-34: one sincos libcall, as above
+    double x = cos_phi * std::sqrt(1.0 - z * z);
+    double y = sin_phi * std::sqrt(1.0 - z * z);
     return Vec3(x, y, z);
 }
 static inline double sq_of_len(const Vec3& v) { double l = v.length(); return l * l; }   // `.length().powi(2)`
