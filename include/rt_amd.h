@@ -51,16 +51,6 @@ enum {
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
-    RT_WAVEFRONT = 128,    /* scheduling only, same samples, BVH scenes only (ignored for list scenes): the frame's paths go through a
-                              pool in HBM in rounds of three kernels — new camera paths / world.hit with lanes that fetch the next
-                              path as soon as their search ends / hit record + material — instead of one persistent kernel.
-                              rt_render_device is synchronous with it; its path pools take up to 4 GB (never more than a quarter of
-                              the device's free memory) and are released when the scene is edited or destroyed.               */
-    RT_DEFER_BVH = 256,    /* scheduling only, same samples (lock-step BVH kernels): a lane whose ray enters a BVH object that few lanes of its
-                              wavefront enter parks its path in a per-wave ring in device memory and takes another one; once 64 paths
-                              wait at such an object the wavefront walks it for all of them at once.  Chosen automatically where it
-                              pays; this flag forces it on ...                                                     */
-    RT_NO_DEFER_BVH = 512, /* ... and this one off                                                                            */
     RT_SPECULATE_BVH = 1024, /* scheduling only, same samples (lock-step BVH kernel): a lane that has reached a leaf walks on while it waits for the
                               leaf step (rt_kernel.hip: bvh_hit_spec).  Chosen automatically for scenes whose world is one BVH (every ray
                               enters it); this flag forces it on ...                                                          */
@@ -179,8 +169,8 @@ int rt_render_device(rt_scene*, const rt_camera*, const double background[3], ui
  * device renders its share with one persistent launch, ONE ncclGather (RCCL over xGMI; communicators from ncclCommInitAll, cached
  * with the scene; librccl is loaded on first use) brings the packed tiles to the first selected device, which un-permutes them on the
  * device; rgb_sum_out receives W*H*3 doubles in output order, as from rt_render.  Synchronous.  A failure on any device leaves
- * nothing in flight, keeps no temporary and restores the caller's current HIP device.  RT_WAVEFRONT is refused with more than one
- * device.  rt_last_multi_ms (waits for the frame): [0] slowest device's kernel, [1] the gather as the first device's stream sees it
+ * nothing in flight, keeps no temporary and restores the caller's current HIP device.
+ * rt_last_multi_ms (waits for the frame): [0] slowest device's kernel, [1] the gather as the first device's stream sees it
  * (from the end of its own kernel: the collective including the wait for the slowest other device), [2] un-permute, [3] host clock
  * from the call's entry to the end of the wait (rt_render_multi: of the whole call, transfer included), in ms. */
 int rt_render_multi(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,

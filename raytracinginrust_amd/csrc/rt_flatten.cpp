@@ -238,7 +238,6 @@ struct Flattener {
         DObject o{};
         o.geom_kind = kind; o.geom_first = first; o.geom_count = count;
         o.first_op = (uint32_t)f.ops.size(); o.n_ops = (uint32_t)chain.n; o.medium = medium;
-        if (kind == G_BVH && medium < 0) o.pad0 = f.n_defer_rings++;      // bare BVH objects, in list order: the ring of the deferred-entry kernels
         for (int i = 0; i < chain.n; i++) f.ops.push_back(chain.ops[i]);
         f.objects.push_back(o);
         return true;

@@ -33,7 +33,7 @@ static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_er
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> static void free_device_scene(DeviceScene<T>& d) {
     free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
-    free_dev(d.bvh); free_dev(d.bvh_soa); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
+    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
     d.valid = false;
 }
 
@@ -69,11 +69,11 @@ void rt_scene_destroy(rt_scene* sc) {
         free_device_scene(c->dev32);
         for (Scene::LaunchSlot& l : c->slots) {
             if (l.recorded) (void)hipEventSynchronize((hipEvent_t)l.ev_stop);
-            free_dev(l.d_queue); free_dev(l.d_stats); free_dev(l.d_defer);
+            free_dev(l.d_queue); free_dev(l.d_stats);
             if (l.ev_start) (void)hipEventDestroy((hipEvent_t)l.ev_start);
             if (l.ev_stop) (void)hipEventDestroy((hipEvent_t)l.ev_stop);
         }
-        free_dev(c->d_tiles); free_dev(c->d_gather); free_dev(c->d_frame); free_dev(c->d_wf);
+        free_dev(c->d_tiles); free_dev(c->d_gather); free_dev(c->d_frame);
         if (c->stream) (void)hipStreamDestroy((hipStream_t)c->stream);
         delete c;
     }
@@ -88,7 +88,6 @@ static void touch(rt_scene* sc) {
     int cur = 0; (void)hipGetDevice(&cur);
     for (Scene::DeviceCtx* c : sc->s.ctxs) {
         (void)hipSetDevice(c->device); free_device_scene(c->dev64); free_device_scene(c->dev32);
-        if (c->d_wf) { (void)hipFree(c->d_wf); c->d_wf = nullptr; c->wf_bytes = 0; }     // the wavefront backend's path pools (GBs) do not outlive a scene edit
     }
     (void)hipSetDevice(cur);
 }
@@ -408,14 +407,6 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DMSphere<T>>(f.mspheres, d.mspheres)) return -1;
     if (upload_vec<DTri<T>>(f.tris, d.tris)) return -1;
     if (upload_vec<DBvhNode<T>>(f.bvh, d.bvh)) return -1;
-    {   // field-wise copy of the nodes (a few KB; only the RT_NODE_SOA measurement build reads it)
-        const size_t n = f.bvh.size();
-        std::vector<T> soa((6 * n + 4 * n) + 8, T(0));                  // u32 a, b, c, skip packed behind the bounds (4n u32 = 4n reals for f32, 2n for f64)
-        for (size_t i = 0; i < n; i++) for (int k = 0; k < 3; k++) { soa[(size_t)k * n + i] = (T)f.bvh[i].mn[k]; soa[(size_t)(3 + k) * n + i] = (T)f.bvh[i].mx[k]; }
-        uint32_t* u = (uint32_t*)(soa.data() + 6 * n);
-        for (size_t i = 0; i < n; i++) { u[i] = f.bvh[i].a; u[n + i] = f.bvh[i].b; u[2 * n + i] = f.bvh[i].c; u[3 * n + i] = f.bvh[i].skip; }
-        if (upload_raw(soa, d.bvh_soa)) return -1;
-    }
     if (upload_vec<DMaterial<T>>(f.materials, d.materials)) return -1;
     if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
     if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
@@ -490,24 +481,13 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
         if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size()) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
-    // Deferred BVH entry (scheduling only): for the reference-order lock-step kernels of scenes in which a BVH object stands beside
-    // other top-level objects (a BVH that IS the world is entered by every ray: nothing to defer)
-    {
-        size_t n_bvh_objects = 0;
-        for (const DObject& ob : f.objects) n_bvh_objects += (ob.geom_kind == G_BVH && ob.medium < 0) ? 1u : 0u;
-        const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && n_bvh_objects != 0 && n_bvh_objects <= RT_MAX_DEFER_RINGS && n_bvh_objects == f.n_defer_rings &&
-                         f.objects.size() > 1 && !(flags & (RT_NEAR_FIRST_BVH | RT_WAVEFRONT));
-        if (!can || (flags & RT_NO_DEFER_BVH)) out &= ~(uint32_t)RT_DEFER_BVH;
-        if (out & RT_DEFER_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
-        if (out & RT_PERSISTENT_BVH) out &= ~(uint32_t)RT_DEFER_BVH;
-    }
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
     // enters it, which is where walking on past an untested leaf pays (*measured* random spheres +2.6 %; scenes whose trees few lanes
     // enter lose 3 %)
     {
         const bool one_bvh = f.objects.size() == 1 && f.objects[0].geom_kind == G_BVH && f.objects[0].medium < 0;
         const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u &&
-                         !(out & (RT_NEAR_FIRST_BVH | RT_WAVEFRONT | RT_PERSISTENT_BVH | RT_DEFER_BVH));
+                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
         if (can && one_bvh && !(flags & RT_NO_SPECULATE_BVH)) out |= RT_SPECULATE_BVH;
         if (!can || (flags & RT_NO_SPECULATE_BVH)) out &= ~(uint32_t)RT_SPECULATE_BVH;
     }
@@ -528,83 +508,6 @@ template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat
     return (uint32_t)std::min(room, f.bvh.size());
 }
 
-// ---------------------------------------------------------------- wavefront backend (RT_WAVEFRONT; BVH scenes)
-// The frame's paths go through a pool of P slots in HBM in rounds of three launches (rt_kernel.hip: wf_gen / wf_trace / wf_shade).
-// The host keeps the book between rounds — how many paths live, how many slots are free, which sample comes next — from two counters
-// it reads back after each round, so this entry point is synchronous (unlike the megakernel launch it returns when the frame is done).
-template <typename T>
-int render_wavefront(Scene::DeviceCtx& c, KParams<T> P, const HostFlat& f, const LaunchShape&, const hipDeviceProp_t& prop,
-                     uint64_t n_local_px, hipStream_t stream) {
-    // the wavefront kernels are the lock-step-family instantiations (never the persistent-traversal one): their workgroup shape
-    P.flags &= ~(uint32_t)(RT_PERSISTENT_BVH | RT_DEFER_BVH);
-    const LaunchShape shape = pathtrace_shape(f.feats, P.flags);
-    // the real (unpadded) local pixels are a prefix of the local range: tile t = rank + q * world grows with q
-    const uint64_t n_px = (uint64_t)P.W * P.H;
-    uint64_t n_real = 0;
-    for (uint32_t q = 0; q < P.n_local_tiles; q++) {
-        const uint64_t first = ((uint64_t)P.rank + (uint64_t)q * P.world) * P.tile_px;
-        if (first >= n_px) break;
-        n_real += std::min<uint64_t>(P.tile_px, n_px - first);
-    }
-    (void)n_local_px;
-    const uint64_t total = n_real * P.spp;
-    uint64_t pool = 16ull << 20;                   // paths in flight: two pools of 128-byte records = 4 GB in f64; *measured* 16 M beats 4 M by 7-15 %
-    if (const char* v = std::getenv("RT_WF_POOL")) { const long long n = std::strtoll(v, nullptr, 10); if (n >= 64 && n <= (1ll << 26)) pool = (uint64_t)n; }
-    if (pool > total) pool = total;
-    {   // never more than a quarter of what the device has free (beside what this context already holds for the pools)
-        size_t mem_free = 0, mem_total = 0;
-        if (hipMemGetInfo(&mem_free, &mem_total) == hipSuccess) {
-            const uint64_t cap = ((uint64_t)mem_free + c.wf_bytes) / 4u / (2u * sizeof(WfPath<T>));
-            if (pool > cap) pool = cap;
-        }
-    }
-    if (pool == 0) return set_err("wavefront backend: no device memory for the path pools");
-    const uint32_t Pn = (uint32_t)pool;
-    // one allocation: the two pools (one aligned record per path) and the counters
-    const size_t need = 2 * (size_t)Pn * sizeof(WfPath<T>) + 256;
-    if (c.wf_bytes < need) {
-        if (c.d_wf) { (void)hipFree(c.d_wf); c.d_wf = nullptr; c.wf_bytes = 0; }
-        HIP_OK(hipMalloc(&c.d_wf, need)); c.wf_bytes = need;
-    }
-    WfParams<T> W; std::memset((void*)&W, 0, sizeof(W));
-    WfPath<T>* pools[2] = {(WfPath<T>*)c.d_wf, (WfPath<T>*)c.d_wf + Pn};
-    W.counters = (uint32_t*)((WfPath<T>*)c.d_wf + 2 * (size_t)Pn);
-    W.P = Pn;
-    auto bind = [&](int cur) { W.in = pools[cur]; W.out = pools[cur ^ 1]; };
-    // LDS of the trace kernel: the top of the BVH beside the waves' stacks (no camera-path queues here)
-    const size_t waves = shape.threads / 64u, stacks = waves * (size_t)P.stack_depth * 256u;
-    size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor; if (lds_total < 65536u) lds_total = 65536u;
-    size_t room = lds_total > stacks ? (lds_total - stacks) / sizeof(DBvhNode<T>) : 0;
-    if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
-    P.n_cached = (uint32_t)std::min(room, f.bvh.size());
-    const size_t shmem = (size_t)P.n_cached * sizeof(DBvhNode<T>) + stacks;
-    uint64_t n_alive = 0, next_sample = 0;
-    int cur = 0;
-    uint32_t rounds = 0;
-    while (true) {
-        const uint64_t n_new = std::min<uint64_t>(Pn - n_alive, total - next_sample);
-        if (n_alive + n_new == 0) break;
-        bind(cur);
-        W.n_alive = (uint32_t)n_alive; W.n_new = (uint32_t)n_new; W.first_sample = next_sample;
-        HIP_OK(launch_wf_gen<T>(P, W, stream));                                   // new camera paths behind the survivors
-        n_alive += n_new; next_sample += n_new;
-        W.n_alive = (uint32_t)n_alive; W.n_new = 0;
-        HIP_OK(hipMemsetAsync(W.counters, 0, 16, stream));
-        uint64_t blocks = (n_alive + shape.threads - 1) / shape.threads;
-        if (blocks > (uint64_t)prop.multiProcessorCount) blocks = (uint64_t)prop.multiProcessorCount;
-        HIP_OK(launch_wf_trace<T>(P, W, f.feats, (uint32_t)blocks, shmem, stream));
-        HIP_OK(launch_wf_shade<T>(P, W, f.feats, stream));                        // survivors -> the other pool, packed
-        uint32_t cnt[4];
-        HIP_OK(hipMemcpyAsync(cnt, W.counters, sizeof(cnt), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
-        if ((uint64_t)cnt[1] > n_alive) return set_err("wavefront round produced more paths than it had (internal error)");
-        n_alive = cnt[1];
-        cur ^= 1;
-        if (++rounds > 4000000u) return set_err("wavefront: too many rounds");
-    }
-    return 0;
-}
-
 template <typename T>
 int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                 uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
@@ -620,7 +523,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.objects = (const DObject*)d.objects; P.n_objects = (uint32_t)f.objects.size();
     P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
-    P.bvh_soa = (const T*)d.bvh_soa; P.n_bvh = (uint32_t)f.bvh.size();
+    P.n_bvh = (uint32_t)f.bvh.size();
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
@@ -705,23 +608,6 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         P.n_chunks = (uint32_t)n_chunks64;
     }
 
-    P.defer_ring = nullptr; P.defer_capacity = 0u; P.defer_dense = 0u; P.defer_rings = 0u; P.defer_stop = 1u;
-    if (P.flags & RT_DEFER_BVH) {
-        // per wavefront of the grid and bare BVH object one ring of parked paths: 256 slots of 128 bytes (up to 63 waiting for the walk +
-        // the 64 just walked + what a step parks on top); 128 MB per object for a chip-filling grid
-        P.defer_capacity = 256u;
-        P.defer_rings = f.n_defer_rings;
-        P.defer_dense = 48u;
-        P.defer_stop = 20u;
-        if (const char* v = std::getenv("RT_DEFER_STOP")) { const long n = std::strtol(v, nullptr, 10); if (n >= 1 && n <= 64) P.defer_stop = (uint32_t)n; }      // A/B runs, tests: 1 = walks run to their end
-        if (const char* v = std::getenv("RT_DEFER_DENSE")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && n <= 65) P.defer_dense = (uint32_t)n; }   // A/B runs, tests: 0 = never park, 65 = always
-        const size_t need = (size_t)n_blocks * waves_per_block * P.defer_rings * P.defer_capacity * 16u * sizeof(double);
-        if (slot->defer_bytes < need) {
-            if (slot->d_defer) { (void)hipFree(slot->d_defer); slot->d_defer = nullptr; slot->defer_bytes = 0; }
-            HIP_OK(hipMalloc(&slot->d_defer, need)); slot->defer_bytes = need;
-        }
-        P.defer_ring = (double*)slot->d_defer;
-    }
     P.trace_out = nullptr; P.trace_px = 0u; P.trace_s = 0u;
     if (s.trace_px >= 0) {                          // debugging aid: 16 doubles per level of one path (written by -DRT_TRACE_PATH builds only)
         const size_t bytes = ((size_t)max_depth + 1u) * 16u * sizeof(double);
@@ -735,11 +621,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     HIP_OK(hipMemsetAsync(slot->d_stats, 0, RT_STATS_BYTES, stream));
     HIP_OK(hipMemsetAsync(d_out, 0, (size_t)n_local_px * 3 * sizeof(double), stream));
     HIP_OK(hipEventRecord((hipEvent_t)slot->ev_start, stream));
-    if ((flags & RT_WAVEFRONT) && shape.one_per_cu) {
-        if (render_wavefront<T>(c, P, f, shape, prop, n_local_px, stream)) return -1;
-    } else {
-        HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
-    }
+    HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
     HIP_OK(hipEventRecord((hipEvent_t)slot->ev_stop, stream));
     slot->recorded = true; slot->timed = false; slot->seq = ++s.launch_seq;
     c.last_slot = (int)(slot - c.slots);

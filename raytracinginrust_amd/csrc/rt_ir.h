@@ -43,11 +43,8 @@ enum Feat : uint32_t {
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
-    F_DEFER = 1u << 9,      // not a scene feature: lock-step loop with deferred entry into sparsely entered BVH objects (RT_DEFER_BVH)
-    F_NO_PLAIN_BVH = 1u << 10,  // (inside the F_DEFER kernels) object_hit without the arm for bare BVH objects: the caller walks those
     F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
-static const uint32_t RT_MAX_DEFER_RINGS = 4u;     // deferrable BVH objects per scene (one ring of parked paths per object and wavefront)
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count, node.c = rank in DFS
                                                    //       preorder (= the reference's visiting order: resolves exact-t ties in near-first mode);
@@ -62,7 +59,7 @@ template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad;
 template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
-struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };   // pad0: a bare BVH object's ring of parked paths (F_DEFER kernels)
+struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 template <typename T> struct alignas(16) DMaterial { uint32_t kind, tex; T albedo[3]; T param; };   // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
@@ -84,8 +81,7 @@ template <typename T> struct KParams {
     const DMSphere<T>* mspheres;
     const DTri<T>* tris;
     const DBvhNode<T>* bvh;
-    const T* bvh_soa; uint32_t n_bvh;      // the same nodes field by field ([6][n_bvh] bounds, then [3][n_bvh] u32 a, b, c): read only by the
-                                           // -DRT_NODE_SOA build, which exists to measure the structure-of-arrays layout
+    uint32_t n_bvh;
     const DMaterial<T>* materials;
     const DTexture<T>* textures;
     const DMedium<T>* media;
@@ -118,32 +114,9 @@ template <typename T> struct KParams {
     // BVH scenes (persistent traversal): a traversal pass starts once trav_hi lanes are inside a BVH and runs until fewer
     // than trav_lo are still walking
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
-    // Deferred BVH entry: rings of parked paths, defer_rings per wavefront (one per bare BVH object, DObject::pad0) of defer_capacity slots (a power of two) each;
-    // an object that at least defer_dense lanes of the wave enter is walked on the spot.
-    // A walk is suspended once fewer than defer_stop lanes are still in it; the stragglers are walked on with the next batch.
-    double* defer_ring; uint32_t defer_capacity, defer_dense, defer_rings, defer_stop;
     // debugging aid (-DRT_TRACE_PATH builds, rt_debug_trace_path): the path (trace_px, trace_s) writes 16 doubles per level to trace_out
     double* trace_out; uint32_t trace_px, trace_s;
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
-};
-
-// Wavefront backend (RT_WAVEFRONT): the paths in flight live in two pools of `P` records in HBM, used in turn: a round reads the live
-// paths at positions [0, n_alive) of one pool and packs the survivors into the other.  One path = ONE aligned record (128 B in f64:
-// a single cache line; 64 B in f32), so that a lane that picks up or hands back a path touches one line, not one line per field.
-template <typename T> struct alignas(16 * sizeof(T)) WfPath {
-    T o[3], d[3], tm;               // the ray (world space) and its time
-    T beta[3];                      // throughput
-    T hit_t; uint32_t hit_obj, hit_prim;     // world.hit's result (hit_obj = 0xFFFFFFFF: no hit): one 16-byte piece in f64
-    uint32_t rng[4];                // xoshiro state
-    uint32_t px, smp, depth;        // local pixel, sample index, bounces left
-};
-template <typename T> struct WfParams {
-    WfPath<T>* in;                  // this round's pool: live paths at [0, n_alive); gen appends n_new behind them
-    WfPath<T>* out;                 // the other pool: shade packs the survivors into it
-    uint32_t P;
-    uint32_t n_alive;
-    uint32_t* counters;             // [1] survivors of the round
-    unsigned long long first_sample; uint32_t n_new;       // gen: sample index (local pixel * spp + sample) of the first new path
 };
 
 } // namespace rt

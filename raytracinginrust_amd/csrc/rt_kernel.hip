@@ -63,12 +63,6 @@
 #ifndef RT_WAVES_PBR
 #define RT_WAVES_PBR 3
 #endif
-// Per-pixel partial sums of the BVH kernels in the lane's LDS column instead of six VGPRs: *measured* (round 2, A/B in one process)
-// slower — random spheres -3.5 %, final scene -2 %, teapot room -6 % (the 24 KB per CU come out of the node cache, and the kernels
-// spill about as much either way) — so registers it is; the option stays for the measurement.
-#ifndef RT_ACC_LDS
-#define RT_ACC_LDS 0
-#endif
 #ifndef RT_WW_NUM
 #define RT_WW_NUM 3u
 #define RT_WW_DEN 8u
@@ -417,25 +411,12 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 // CU: the BVH kernels run one workgroup per CU) and a visit there is four ds_read_b128 instead of four global loads.
 template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t node) {
     if (node < P.n_cached) return *(const DBvhNode<T>*)(lds_raw + node * (uint32_t)sizeof(DBvhNode<T>));
-#ifdef RT_NODE_SOA      // measurement build only: the north_star's field-wise structure-of-arrays node layout
-    DBvhNode<T> nd;
-    const uint32_t n = P.n_bvh;
-    for (uint32_t k = 0; k < 3u; k++) { nd.mn[k] = cl(P.bvh_soa + k * n + node); nd.mx[k] = cl(P.bvh_soa + (3u + k) * n + node); }
-    const uint32_t* u = (const uint32_t*)(P.bvh_soa + 6u * n);
-    nd.a = cl(u + node); nd.b = cl(u + n + node); nd.c = cl(u + 2u * n + node); nd.skip = cl(u + 3u * n + node);
-    return nd;
-#else
     return ld_node_at(P.bvh, node);
-#endif
 }
 
-// `root` is the node a lane's walk starts (or, after a suspension, goes on) at.  `stop_below` > 1 (reference order only) suspends the
-// search as soon as fewer lanes than that are still walking — after a leaf step, so no leaf is pending: the stragglers' next node comes
-// back in `next_node` (0xFFFFFFFF: finished) and their running closest hit in t_out / prim_out, and the caller resumes them later, with
-// company, from exactly that state (trace_deferred).
+// `root` is the node a lane's walk starts at.
 template <typename T, uint32_t FEATS>
-DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack,
-                    uint32_t stop_below = 1u, uint32_t* next_node = nullptr) {
+DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
     V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
     T closest = t_max;
     bool any = false;
@@ -490,9 +471,8 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                 bvh_accept(near_first, t, closest, leaf_node, best_leaf)) { closest = t; prim_out = prim; any = true; best_leaf = leaf_node; }
             have_leaf = false;
         }
-        if ((uint32_t)__popcll(__ballot(node != DONE)) < stop_below) break;          // every lane of the wave is finished (or few enough are left)
+        if (__ballot(node != DONE) == 0ull) break;          // every lane of the wave is finished
     }
-    if (next_node) *next_node = node;
     t_out = closest;
     return any;
 }
@@ -559,10 +539,9 @@ DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
 }
 
 template <typename T, uint32_t FEATS>
-DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack,
-                 uint32_t stop_below = 1u, uint32_t* next_node = nullptr) {
-    if ((RT_SPECULATE || (FEATS & F_SPEC)) && !(FEATS & F_NEAR_FIRST) && next_node == nullptr) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
-    return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack, stop_below, next_node);
+DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
+    if ((RT_SPECULATE || (FEATS & F_SPEC)) && !(FEATS & F_NEAR_FIRST)) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
+    return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack);
 }
 
 // ------------------------------------------------------------------ wrapper chain (translate.rs, rotate.rs, hit.rs FlipNormal)
@@ -601,8 +580,7 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
         T t; uint32_t prim;
-        // (F_NO_PLAIN_BVH: the caller walks bare BVH objects itself — trace_deferred — so that arm is compiled out of this copy)
-        if (geom_hit<T, (FEATS & F_NO_PLAIN_BVH) ? (FEATS & ~(uint32_t)F_BVH) : FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     } else {
         // ConstantMedium::hit, medium.rs:27-61
         T t1, t2; uint32_t p1, p2;
@@ -1014,10 +992,8 @@ template <typename T> DEV V3<T> brdf_pdf_generate(const DPbr<T>& m, const Onb<T>
     return onb_local(uvw, reflect_(r_in, wh));
 }
 
-// A lane's partial sum of one pixel: three f64.  In registers for the list-scene kernels; the BVH kernels keep it in the lane's LDS
-// column instead (touched once per finished path, it would otherwise sit in — or be spilled from — six VGPRs through every traversal).
+// A lane's partial sum of one pixel: three f64 in registers (LDS instead was measured and is slower: docs/history.md).
 struct AccReg { double v[3]; DEV double get(int k) const { return v[k]; } DEV void set(int k, double x) { v[k] = x; } };
-struct AccLds { double* col; DEV double get(int k) const { return col[k * 64]; } DEV void set(int k, double x) { col[k * 64] = x; } };
 
 // ------------------------------------------------------------------ launch geometry per kernel family
 // List scenes: 256-thread workgroups, several per CU.  BVH scenes: ONE workgroup per CU holding every wave the register budget
@@ -1029,11 +1005,7 @@ template <uint32_t FEATS> struct Shape {
     static constexpr uint32_t WAVES = ONE_PER_CU ? 4u * WAVES_PER_SIMD : 4u;
     static constexpr uint32_t THREADS = 64u * WAVES;
     static constexpr uint32_t QN_MIN = ONE_PER_CU ? 16u : 64u;    // camera-path queue entries per wave: at least this, up to 64 (KParams::queue_entries)
-    static constexpr bool ACC_IN_LDS = RT_ACC_LDS && ONE_PER_CU;  // per-pixel partial sums in the lane's LDS column (1.5 KB per wave)
-    typedef typename std::conditional<ACC_IN_LDS, AccLds, AccReg>::type Acc;
-    static DEV Acc make_acc(double* col) { Acc a; assign_acc(a, col); return a; }
-    static DEV void assign_acc(AccLds& a, double* col) { a.col = col; }
-    static DEV void assign_acc(AccReg&, double*) {}
+    typedef AccReg Acc;
 };
 
 // ------------------------------------------------------------------ wave helpers
@@ -1335,7 +1307,7 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
 // wave-uniform object list, hit record, material).  Used when the scene has no BVH: every lane's closest-hit search costs
 // the same, so lock-step wastes nothing.
 template <typename T, uint32_t FEATS>
-DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack, double* acc_col) {
+DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack) {
     WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
     // per-lane path state
     bool alive = false;
@@ -1345,7 +1317,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
-    typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
+    typename Shape<FEATS>::Acc acc;
     acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0;
@@ -1390,19 +1362,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
                     Rec<T> rec;
                     finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
                     DIAG_ADD(3);
-#ifdef RT_REC_LDS       // measurement build only: the north_star's "current hit record staged in LDS" — the record goes
-                        // through the lane's LDS column (here: the wave's BVH-stack area, unused in list scenes) between hit and material
-                    {
-                        T* col = (T*)(stack - (threadIdx.x & 63u)) + (threadIdx.x & 63u);
-                        col[0 * 64] = rec.p.x; col[1 * 64] = rec.p.y; col[2 * 64] = rec.p.z; col[3 * 64] = rec.n.x; col[4 * 64] = rec.n.y; col[5 * 64] = rec.n.z;
-                        col[6 * 64] = rec.t; col[7 * 64] = rec.u; col[8 * 64] = rec.v;
-                        uint32_t* cu = (uint32_t*)(col - (threadIdx.x & 63u) + 9 * 64) + (threadIdx.x & 63u);
-                        cu[0] = rec.front ? 1u : 0u; cu[64] = rec.mat;
-                        __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
-                        rec.p = mk<T>(col[0 * 64], col[1 * 64], col[2 * 64]); rec.n = mk<T>(col[3 * 64], col[4 * 64], col[5 * 64]);
-                        rec.t = col[6 * 64]; rec.u = col[7 * 64]; rec.v = col[8 * 64]; rec.front = cu[0] != 0u; rec.mat = cu[64];
-                    }
-#endif
 #ifdef RT_TRACE_PATH    // debugging build only (tools/fuzz_probe.py): the hits of one path, level by level, for comparison with the oracle's orc_trace_path
                     if (P.trace_out && path_px == P.trace_px && path_s == P.trace_s && depth_left <= P.max_depth) {
                         double* o = P.trace_out + 16u * (P.max_depth - depth_left);
@@ -1435,246 +1394,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 #endif
 }
 
-// ------------------------------------------------------------------ BVH scenes: lock-step loop with deferred BVH entry
-// A BVH object that stands beside others is entered by a minority of a wave's lanes — *measured* (round 3, -DRT_DIAG_OBJ) per
-// `world.hit` call of the final scene: 27 of 59 lanes pass the root box of the ground boxes' tree, 12 that of the sphere cluster's;
-// teapot room: 26 of 63 — and those then walk a hundred nodes while the others wait: 88 % of that scene's `world.hit` time, half the
-// frame, at a quarter of the lanes.  Here a lane whose ray passes the root box of such an object (fewer than P.defer_dense lanes of the
-// wave do) does not walk it on the spot.  It PARKS its whole path — ray, closest hit so far, throughput, RNG state, pixel, sample: 128
-// bytes — in the wave's ring for that object in device memory.  Once 64 paths wait there, the wave walks the tree for all of them at
-// once, right at that object's place in the list and through the same code that walks it when most lanes enter; the results go back
-// to the ring.  A lane that has just parked takes a walked path out of the ring in exchange and goes on with it — the objects behind
-// the BVH, the material — so no lane waits for a walk and no lane idles after parking.
-// A path's own sequence of operations (objects in push order, bbox / left / right, shrinking t_max, RNG draws) is untouched, so every
-// sample is bit-identical to the plain lock-step loop; what changes is which lane runs which part of it when, i.e. the order in which a
-// pixel's samples are summed (deviation D3).
-// Rings: one per deferrable object (DObject::pad0, at most RT_MAX_DEFER_RINGS) and wave, `defer_capacity` slots, 16 columns of 8
-// bytes, column-major ([column][slot]: consecutive lanes use consecutive slots).  Indices grow monotonically, slot = index &
-// (capacity - 1): [done, wait) walked, waiting for a lane; [wait, tail) parked, waiting for the walk.  Lane r of the wave keeps ring
-// r's three indices (read with v_readlane).  A walk reads what earlier instructions of the same wave stored and vice versa: ordered
-// by workgroup-scope fences.
-struct DeferCtl { uint32_t done, wait, tail; };
-// one parked path: the world-space ray, the closest hit of its list search so far (any_hit rides on the depth word), throughput, RNG
-// state, bounces left, pixel, sample, and the node its walk of this tree starts or goes on at
-enum : uint32_t { DC_OX = 0, DC_OY, DC_OZ, DC_DX, DC_DY, DC_DZ, DC_TM, DC_CLOSEST, DC_BX, DC_BY, DC_BZ, DC_RNG01, DC_RNG23, DC_ID, DC_DEPTH_PX, DC_S_NODE, DC_COLS };
-static_assert(DC_COLS == 16u, "a parked path is 16 columns of 8 bytes");
-DEV double pack2(uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo)); }
-DEV void unpack2(double x, uint32_t& lo, uint32_t& hi) { const unsigned long long u = (unsigned long long)__double_as_longlong(x); lo = (uint32_t)u; hi = (uint32_t)(u >> 32); }
-DEV uint32_t rlane(uint32_t v, uint32_t l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l); }
-template <typename T>
-DEV void defer_store(double* b, uint32_t C, const RayT<T>& ray, T closest, HitId id, bool any_hit, V3<T> beta, const Rng& rng, uint32_t depth_left,
-                     uint32_t path_px, uint32_t path_s, uint32_t node) {
-    b[DC_OX * C] = (double)ray.o.x; b[DC_OY * C] = (double)ray.o.y; b[DC_OZ * C] = (double)ray.o.z;
-    b[DC_DX * C] = (double)ray.d.x; b[DC_DY * C] = (double)ray.d.y; b[DC_DZ * C] = (double)ray.d.z;
-    b[DC_TM * C] = (double)ray.tm; b[DC_CLOSEST * C] = (double)closest;
-    b[DC_BX * C] = (double)beta.x; b[DC_BY * C] = (double)beta.y; b[DC_BZ * C] = (double)beta.z;
-    b[DC_RNG01 * C] = pack2(rng.s0, rng.s1); b[DC_RNG23 * C] = pack2(rng.s2, rng.s3);
-    b[DC_ID * C] = pack2(id.obj, id.prim);
-    b[DC_DEPTH_PX * C] = pack2(depth_left | (any_hit ? 0x80000000u : 0u), path_px);
-    b[DC_S_NODE * C] = pack2(path_s, node);
-}
-
-template <typename T, uint32_t FEATS>
-DEV void trace_deferred(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack, double* acc_col, double* rings) {
-    WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
-    DeferCtl ctl; ctl.done = ctl.wait = ctl.tail = 0u;
-    const uint32_t C = P.defer_capacity;
-    const uint32_t DONE = 0xFFFFFFFFu;
-    // per-lane path state
-    bool alive = false;
-    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
-    V3<T> beta = mk<T>(T(0), T(0), T(0));
-    uint32_t depth_left = 0, path_px = 0, path_s = 0;
-    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    uint32_t acc_px = NONE_PX;
-    typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
-    acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
-    uint32_t n_nonfinite = 0, n_flush = 0;
-    unsigned long long n_iters = 0, n_active = 0, n_walks = 0, n_walk_lanes = 0, n_parked = 0;
-    DIAG_DECL       // (-DRT_DIAG: [0] new paths + flush, [1] list objects, [2] root tests + parking, [3] tree walks, [4] taking walked paths, [5] hit record + material)
-    DIAG_T0();
-
-    for (;;) {
-        // ---- lanes whose path has ended take the next camera path from the wave's queue
-        uint32_t new_px = 0;
-        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
-        const bool draining = w.queue_done && w.q_count == 0u;       // no camera path left: parked paths are walked as they come
-        if (__ballot(alive || got_new) == 0 && __ballot(lane < P.defer_rings && ctl.tail != ctl.done) == 0) break;    // no path anywhere
-        // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
-        if (got_new) {
-            if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
-            path_px = new_px;
-            beta = mk<T>(T(1.0), T(1.0), T(1.0));
-            depth_left = P.max_depth;
-            alive = true;
-        }
-        n_iters++;
-        n_active += (unsigned long long)__popcll(__ballot(alive));
-        DIAG_ADD(0);
-
-        // ---- one level of ray_color (main.rs:41-120) for every live lane
-        bool spent = alive && depth_left == 0u;         // main.rs:42-45: the sample is beta * 0
-        bool vacant = false;                            // this lane's path was parked in this iteration and nothing came in exchange
-        T closest = Lim<T>::inf(); HitId id; id.obj = 0; id.prim = 0; bool any_hit = false;
-        // world.hit (main.rs:48): the top-level list in push order (hit.rs:59-71)
-        for (uint32_t oi = 0; oi < P.n_objects; oi++) {
-            const DObject ob = ld_obj(P.objects + oi);
-            const bool act = alive && !spent && !vacant;
-            if (!(ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0))) {
-                if (act) object_hit<T, FEATS | F_NO_PLAIN_BVH>(P, oi, ob, ray, TMin<T>::v(), rng, closest, id, any_hit, stack);
-                DIAG_ADD(1);
-                continue;
-            }
-            // ---- a BVH object.  AABB::hit of the tree's root is what BVH::hit does first (bvh.rs:78): who enters?
-            const uint32_t ring = ob.pad0;
-            double* const base = rings + (size_t)ring * (size_t)(C * DC_COLS);
-            uint32_t h_done = rlane(ctl.done, ring), h_wait = rlane(ctl.wait, ring), tail = rlane(ctl.tail, ring);
-            RayT<T> r = ray;
-            for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
-            bool enter;
-            {
-                const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
-                enter = act && box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, TMin<T>::v(), closest);
-            }
-            const unsigned long long em = __ballot(enter);
-            const uint32_t n_enter = (uint32_t)__popcll(em);
-            const uint32_t room = C - (tail - h_done);
-            // most lanes enter (or the ring is full): walk on the spot, as the plain lock-step loop does
-            const bool dense = n_enter >= P.defer_dense || n_enter > room;
-            if (!dense && n_enter != 0u) {
-                if (enter) {
-                    defer_store(base + ((tail + lane_rank(em)) & (C - 1u)), C, ray, closest, id, any_hit, beta, rng, depth_left, path_px, path_s, ob.geom_first);
-                    vacant = true;
-                }
-                tail += n_enter; n_parked += n_enter;
-            }
-            DIAG_ADD(2);
-            const uint32_t n_wait = tail - h_wait;
-            const bool walk = !dense && (n_wait >= 64u || (n_wait != 0u && draining));
-            if (walk || (dense && n_enter != 0u)) {
-                // BVH::hit (bvh.rs:77-91): for the wave's own entering rays, or for the oldest (up to) 64 parked ones.  A walk of parked
-                // paths is suspended once fewer than defer_stop lanes are still in it: the stragglers stay in the ring with the node they
-                // stand at and are walked on together with the next batch — nobody waits for the longest ray of a batch.
-                const uint32_t n_w = n_wait < 64u ? n_wait : 64u;
-                // (a walk of the wave's own rays runs to its end: its stragglers would have to wait in the ring for a walk that a wave
-                // whose lanes keep entering together never starts)
-                const uint32_t stop_below = (walk && !draining) ? P.defer_stop : 1u;
-                RayT<T> tr = r; T tcl = closest; bool part = enter; uint32_t node = ob.geom_first, s_keep = 0;
-                double* wb = base + ((h_wait + lane) & (C - 1u));
-                if (walk) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // the stores that parked these paths (this or earlier iterations)
-                    part = lane < n_w;
-                    if (part) {
-                        tr.o = mk<T>((T)wb[DC_OX * C], (T)wb[DC_OY * C], (T)wb[DC_OZ * C]);
-                        tr.d = mk<T>((T)wb[DC_DX * C], (T)wb[DC_DY * C], (T)wb[DC_DZ * C]);
-                        tr.tm = (T)wb[DC_TM * C]; tcl = (T)wb[DC_CLOSEST * C];
-                        unpack2(wb[DC_S_NODE * C], s_keep, node);
-                        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), tr);
-                    }
-                    n_walks++; n_walk_lanes += n_w;
-                }
-                if (!part) { tr.o = mk<T>(T(0), T(0), T(0)); tr.d = mk<T>(T(1.0), T(1.0), T(1.0)); node = DONE; }     // (idle lanes: a tame ray, no node)
-                T t; uint32_t prim, next = DONE;
-                const bool hit = bvh_hit<T, FEATS>(P, node, tr, TMin<T>::v(), tcl, t, prim, stack, stop_below, &next);
-                const bool straggler = part && next != DONE;
-                const unsigned long long sm = __ballot(straggler);
-                if (walk) {
-                    // results into the ring; the batch's slots are re-dealt so that the finished paths come first ([done, wait) grows by
-                    // them) and the stragglers stay at the head of the waiting ones
-                    const unsigned long long fm = __ballot(part && !straggler);
-                    const uint32_t n_fin = (uint32_t)__popcll(fm);
-                    if (sm == 0ull) {
-                        if (part && hit) {
-                            uint32_t dw, px; unpack2(wb[DC_DEPTH_PX * C], dw, px);
-                            wb[DC_CLOSEST * C] = (double)t; wb[DC_ID * C] = pack2(oi, prim); wb[DC_DEPTH_PX * C] = pack2(dw | 0x80000000u, px);
-                        }
-                    } else {
-                        double col[DC_COLS];
-                        if (part) {
-#pragma unroll
-                            for (uint32_t c = 0; c < DC_COLS; c++) col[c] = wb[c * C];
-                            if (hit) {
-                                uint32_t dw, px; unpack2(col[DC_DEPTH_PX], dw, px);
-                                col[DC_CLOSEST] = (double)t; col[DC_ID] = pack2(oi, prim); col[DC_DEPTH_PX] = pack2(dw | 0x80000000u, px);
-                            }
-                            col[DC_S_NODE] = pack2(s_keep, next);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // every lane holds its path before any slot is overwritten
-                        if (part) {
-                            double* nb = base + ((h_wait + (straggler ? n_fin + lane_rank(sm) : lane_rank(fm))) & (C - 1u));
-#pragma unroll
-                            for (uint32_t c = 0; c < DC_COLS; c++) nb[c * C] = col[c];
-                        }
-                    }
-                    h_wait += n_fin;
-                } else if (part && hit) { closest = t; id.obj = oi; id.prim = prim; any_hit = true; }
-            }
-            DIAG_ADD(3);
-            // ---- lanes without a path take walked ones out of the ring and go on with them behind this object
-            const uint32_t n_done = h_wait - h_done;
-            if (n_done != 0u) {
-                const bool free_lane = vacant || !alive;
-                const unsigned long long want = __ballot(free_lane);
-                if (want != 0ull) {
-                    const uint32_t n_want = (uint32_t)__popcll(want), k = n_want < n_done ? n_want : n_done;
-                    const uint32_t rank = lane_rank(want);
-                    const bool take = free_lane && rank < k;
-                    uint32_t in_px = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the walk's stores
-                    if (take) {
-                        const double* b = base + ((h_done + rank) & (C - 1u));
-                        ray.o = mk<T>((T)b[DC_OX * C], (T)b[DC_OY * C], (T)b[DC_OZ * C]);
-                        ray.d = mk<T>((T)b[DC_DX * C], (T)b[DC_DY * C], (T)b[DC_DZ * C]);
-                        ray.tm = (T)b[DC_TM * C]; closest = (T)b[DC_CLOSEST * C];
-                        beta = mk<T>((T)b[DC_BX * C], (T)b[DC_BY * C], (T)b[DC_BZ * C]);
-                        unpack2(b[DC_RNG01 * C], rng.s0, rng.s1); unpack2(b[DC_RNG23 * C], rng.s2, rng.s3);
-                        unpack2(b[DC_ID * C], id.obj, id.prim);
-                        uint32_t dw; unpack2(b[DC_DEPTH_PX * C], dw, in_px);
-                        depth_left = dw & 0x7FFFFFFFu; any_hit = (dw & 0x80000000u) != 0u;
-                        uint32_t node_unused; unpack2(b[DC_S_NODE * C], path_s, node_unused);
-                    }
-                    h_done += k;
-                    flush_acc(take && acc_px != NONE_PX && acc_px != in_px, acc_px, acc, P.out, lane, n_flush);
-                    if (take) {
-                        if (acc_px != in_px) { acc_px = in_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
-                        path_px = in_px; alive = true; vacant = false; spent = false;
-                    }
-                }
-            }
-            if (lane == ring) { ctl.done = h_done; ctl.wait = h_wait; ctl.tail = tail; }
-            DIAG_ADD(4);
-        }
-        if (vacant) alive = false;                      // the path lives in a ring now
-        if (alive) {
-            bool done = spent;
-            V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
-            if (!spent) {
-                if (!any_hit) {
-                    e = ld3(P.background); done = true;                                     // main.rs:118
-                } else {
-                    Rec<T> rec;
-                    finalize_hit<T, FEATS>(P, ray, closest, id, true, rec);
-                    shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
-                }
-            }
-            if (done) {
-                add_radiance(P, beta * e, acc, n_nonfinite, path_px, path_s);
-                alive = false;
-            }
-        }
-        DIAG_ADD(5);
-    }
-    // ---- the queue is empty: hand in what is left
-    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
-    unsigned long long* const st = stats_row(P.stats);
-    write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
-    if (st && lane == 0) { atomicAdd(&st[9], n_walks); atomicAdd(&st[10], n_walk_lanes); atomicAdd(&st[12], n_parked); }
-#ifdef RT_DIAG
-    if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
-#endif
-}
-
 // ------------------------------------------------------------------ BVH scenes: resumable closest-hit search, persistent traversal
 // With a BVH in the scene the cost of `world.hit` differs wildly between lanes (a ray that misses the root box is done
 // after one node, its neighbour walks a hundred), and in lock-step every lane waits for the slowest one: *measured* VALU
@@ -1692,7 +1411,7 @@ DEV void trace_deferred(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 enum : uint32_t { PH_NEW = 0u, PH_OBJ = 1u, PH_BVH = 2u, PH_SHADE = 3u };
 
 template <typename T, uint32_t FEATS>
-DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack, double* acc_col) {
+DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t* q_u32, uint32_t* stack) {
     WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
     const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;
     // per-lane path state
@@ -1713,7 +1432,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
     bool tv_any = false, tv_have_leaf = false;
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
-    typename Shape<FEATS>::Acc acc = Shape<FEATS>::make_acc(acc_col);
+    typename Shape<FEATS>::Acc acc;
     acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0, n_leaf_steps = 0, n_leaf_lanes = 0;   // steps: box steps
@@ -1883,7 +1602,6 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
 template <typename T, uint32_t FEATS>
 __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER_SIMD) pathtrace_kernel(const KParams<T> P) {
     // dynamic LDS: [n_cached BVH nodes] [WAVES][regen_bytes(queue_entries)] camera-path queues [WAVES][stack_depth][64] BVH stacks
-    //              [WAVES][3][64] f64 per-pixel partial sums (BVH kernels)
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
     const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
@@ -1902,11 +1620,8 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     T* q_real = (T*)regen;                                         // [7][QN]: o.x o.y o.z d.x d.y d.z time
     uint32_t* q_u32 = (uint32_t*)(regen + 7u * QN * sizeof(T));    // [6][QN]: rng s0..s3, local pixel, sample
     uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
-    double* acc_col = (double*)(lds_raw + nodes_bytes + S::WAVES * (regen_bytes(QN) + P.stack_depth * 256u)) + wave_in_block * (3u * 64u) + lane;   // (ACC_IN_LDS kernels)
-    if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col);
-    else if (FEATS & F_DEFER) trace_deferred<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col,
-                                                       P.defer_ring + (size_t)(blockIdx.x * S::WAVES + wave_in_block) * (size_t)(P.defer_rings * P.defer_capacity * DC_COLS));
-    else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack, acc_col);
+    if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack);
+    else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack);
 }
 
 // ------------------------------------------------------------------ launch
@@ -1930,7 +1645,7 @@ static int occupancy_one(size_t shmem) {
     if (Shape<FEATS>::ONE_PER_CU && nb > 1) nb = 1;       // the register budget is set for exactly one such workgroup per CU
     return nb;
 }
-template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN_MIN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; g.acc_in_lds = Shape<FEATS>::ACC_IN_LDS; return g; }
+template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN_MIN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; return g; }
 
 // Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
 // Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
@@ -1959,16 +1674,13 @@ template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<do
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
-    const bool df = (flags & 256u) && (scene_feats & F_BVH) && !nf && !ps;     // RT_DEFER_BVH (reference-order lock-step family only)
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
-        if (df) return f(std::integral_constant<uint32_t, FEATS_MESH | F_DEFER>());
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
-        if ((flags & 1024u) && !nf && !ps && !df) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
-        if (df) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_DEFER>());
+        if ((flags & 1024u) && !nf && !ps) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
     }
@@ -1990,373 +1702,6 @@ template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, u
 template hipError_t launch_pathtrace<float>(const KParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
 template int pathtrace_blocks_per_cu<double>(uint32_t, uint32_t, size_t);
 template int pathtrace_blocks_per_cu<float>(uint32_t, uint32_t, size_t);
-#endif
-
-#if RT_TU != 1
-// ================================================================== wavefront backend for BVH scenes (RT_WAVEFRONT, opt-in)
-// The same per-path arithmetic in the same order, scheduled differently: the paths of a frame live in a pool in HBM (structure of
-// arrays, one slot per path in flight) and every bounce is three launches —
-//   wf_gen    fills free slots with new camera paths (main.rs:813-820)
-//   wf_trace  world.hit for every live path: persistent waves whose lanes FETCH THE NEXT PATH the moment their own search ends, so
-//             a wave's occupancy does not decay to its slowest ray; no material code, no path state besides the ray and its RNG in
-//             registers
-//   wf_shade  hit record + material for every live path, one thread each; finished paths add their radiance to the frame
-//             (partial sums of a wave's lanes that share a pixel are combined first), survivors and freed slots are listed for the
-//             next round.
-// What the megakernel cannot do for BVH scenes — keep traversal lanes busy while neighbours of the same wave finish early, without
-// holding the material code's registers — is the point; the price is ~0.5 KB of HBM traffic per bounce for the path state.
-template <typename T> DEV void wf_camera_path(const KParams<T>& P, uint32_t gp, uint32_t gi, uint32_t gj, uint32_t s, RayT<T>& ray, Rng& g) {
-    g = rng_for_path(P.seed, gp, s);
-    T random_u = rng_u01(g, T(0));
-    T random_v = rng_u01(g, T(0));
-    T u = (T(gi) + random_u) / T(P.W - 1u);
-    T v = (T(gj) + random_v) / T(P.H - 1u);
-    T da, db;                                                   // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
-    for (;;) {
-        da = rng_range(g, T(-1.0), T(1.0));
-        db = rng_range(g, T(-1.0), T(1.0));
-        V3<T> pd = mk<T>(da, db, T(0));
-        if (dot(pd, pd) < T(1.0)) break;
-    }
-    V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
-    V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
-    ray.tm = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
-    ray.o = ld3(P.cam.origin) + offset;
-    ray.d = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
-}
-
-static const uint32_t WF_NO_HIT = 0xFFFFFFFFu;
-// whole-record transfers of a path (one aligned record = one or two cache lines): 16-byte pieces
-template <typename T> DEV void wf_store(WfPath<T>* dst, const WfPath<T>& r) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const u4* s = (const u4*)&r; u4* d = (u4*)dst;
-#pragma unroll
-    for (uint32_t k = 0; k < sizeof(WfPath<T>) / 16u; k++) d[k] = s[k];
-}
-template <typename T> DEV WfPath<T> wf_load(const WfPath<T>* src) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    WfPath<T> r; u4* d = (u4*)&r; const u4* s = (const u4*)src;
-#pragma unroll
-    for (uint32_t k = 0; k < sizeof(WfPath<T>) / 16u; k++) d[k] = s[k];
-    return r;
-}
-
-template <typename T>
-__global__ void __launch_bounds__(256) wf_gen_kernel(const KParams<T> P, const WfParams<T> W) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= W.n_new) return;
-    const uint32_t slot = W.n_alive + i;                                   // new paths join the pool behind the survivors
-    const unsigned long long g = W.first_sample + i;
-    const uint32_t lp = (uint32_t)(g / P.spp), smp = (uint32_t)(g - (unsigned long long)lp * P.spp);
-    const uint32_t q = lp / P.tile_px, kk = lp - q * P.tile_px;
-    const uint32_t gp = (P.rank + q * P.world) * P.tile_px + kk;           // local pixel -> output-order pixel (tile t = rank + q * world)
-    const uint32_t row = gp / P.W, gi = gp - row * P.W, gj = P.H - 1u - row;
-    RayT<T> ray; Rng rng;
-    wf_camera_path(P, gp, gi, gj, smp, ray, rng);
-    WfPath<T> rec;
-    rec.o[0] = ray.o.x; rec.o[1] = ray.o.y; rec.o[2] = ray.o.z; rec.d[0] = ray.d.x; rec.d[1] = ray.d.y; rec.d[2] = ray.d.z; rec.tm = ray.tm;
-    rec.beta[0] = rec.beta[1] = rec.beta[2] = T(1.0); rec.hit_t = T(0);
-    rec.rng[0] = rng.s0; rec.rng[1] = rng.s1; rec.rng[2] = rng.s2; rec.rng[3] = rng.s3;
-    rec.hit_obj = WF_NO_HIT; rec.hit_prim = 0; rec.px = lp; rec.smp = smp; rec.depth = P.max_depth;
-    wf_store(W.in + slot, rec);
-}
-
-// world.hit for every live path.  A lane's search is the state machine of trace_resumable (objects in push order; a BVH object is
-// walked node by node with the stack in the lane's LDS column; box and leaf steps chosen by vote), and what replaces the advance
-// pass is small: store a finished search's (t, object, primitive, RNG) and load the next path of the wave's prefetched batch.
-template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER_SIMD) wf_trace_kernel(const KParams<T> P, const WfParams<T> W) {
-    typedef Shape<FEATS> S;
-    const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
-    if (P.n_cached != 0u) {
-        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4* src = (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
-        for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
-        __syncthreads();
-    }
-    uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes) + wave_in_block * (P.stack_depth * 64u) + lane;
-    const bool near_first = (FEATS & F_NEAR_FIRST) != 0u;
-    const uint32_t NONE = 0xFFFFFFFFu, BVH_DONE = 0xFFFFFFFFu;
-    // the wave's current batch of pool positions: one per lane, handed out front to back.  Batches of 64 consecutive positions are
-    // dealt round-robin over the grid's waves (no shared cursor: one address takes only ~88 atomics per microsecond and a round
-    // has 65 k batches); the lanes inside a wave are what balances the load.
-    uint32_t batch_slot = NONE, q_head = 0, q_count = 0;
-    bool list_done = false;
-    const uint32_t n_waves_grid = gridDim.x * S::WAVES;
-    uint32_t next_batch = blockIdx.x * S::WAVES + wave_in_block;
-    // per-lane search state
-    uint32_t slot = NONE, phase = PH_NEW, my_oi = 0;
-    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
-    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    T closest = Lim<T>::inf();
-    HitId id; id.obj = 0; id.prim = 0;
-    bool any_hit = false;
-    uint32_t tv_node = 0, tv_sp = 0, tv_prim = 0, tv_best = 0, tv_leaf_a = 0, tv_leaf_b = 0, tv_leaf_node = 0;
-    T tv_closest = T(0);
-    bool tv_any = false, tv_have_leaf = false;
-    // ONE ray per lane: the world-space ray while the lane walks the object list; on entering a BVH object it is replaced by the
-    // object-space ray (the wrapper chain applied) and, when that BVH is done, read back from the pool — the traversal loop then
-    // carries 14 registers less, which is what keeps 1/d (`inv`) out of scratch there.
-    V3<T> inv = ray.o;                           // 1/d of the object-space ray (aabb.rs:21), same value at every node
-    unsigned long long n_iters = 0, n_active = 0, n_steps = 0, n_step_lanes = 0;      // rt_last_traversal_stats
-    DIAG_DECL
-    DIAG_T0();
-
-    for (;;) {
-        const uint32_t n_bvh = (uint32_t)__popcll(__ballot(phase == PH_BVH));
-        const bool work_left = !(list_done && q_count == 0u);
-        const uint32_t n_adv = (uint32_t)__popcll(__ballot(phase == PH_OBJ || (phase == PH_NEW && work_left)));
-        if (n_bvh == 0u && n_adv == 0u) break;
-
-        if (n_bvh >= P.trav_hi || n_adv == 0u) {
-            // ================= traversal pass: until trav_lo lanes are left walking (the others wait for the next hand-over)
-            const T t_min = TMin<T>::v();
-            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !ray_is_tame(ray.o, inv)) == 0ull;
-            uint32_t stop_below = P.trav_lo < n_bvh ? P.trav_lo : n_bvh;
-            if (!work_left && n_adv == 0u) stop_below = 1u;         // nothing to hand over any more: run the stragglers out
-            if (stop_below < 1u) stop_below = 1u;
-            // (the step loop of trace_resumable: box steps in an inner loop of their own, RT_BOX_STEPS_PERSIST per vote; the reference's
-            // order walks along the skip links, the nearer-first order keeps the LDS stack)
-            const bool act = phase == PH_BVH;
-            for (;;) {
-                bool few = false;
-                for (;;) {
-                    const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
-                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(act && tv_have_leaf));
-                    few = n_box + n_leaf < stop_below;
-                    if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
-                    auto box_step = [&]() {
-                        const DBvhNode<T> nd = fetch_node(P, tv_node);
-                        const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, tv_closest) : box_inside_exact(nd, ray.o, inv, t_min, tv_closest);
-                        if (!near_first) {
-                            if (inside && (nd.a & BVH_LEAF)) tv_have_leaf = true;             // the leaf stays the lane's node until it has been tested
-                            else tv_node = inside ? nd.c : nd.skip;
-                        } else if (inside && !(nd.a & BVH_LEAF)) {
-                            const bool right_first = get(ray.d, nd.a) < T(0);
-                            stack[tv_sp * 64u] = right_first ? nd.c : nd.b;
-                            tv_sp++;
-                            tv_node = right_first ? nd.b : nd.c;
-                        } else {
-                            if (inside) { tv_have_leaf = true; tv_leaf_a = nd.a; tv_leaf_b = nd.b; tv_leaf_node = nd.c; }
-                            if (tv_sp == 0u) tv_node = BVH_DONE;
-                            else { tv_sp--; tv_node = stack[tv_sp * 64u]; }
-                        }
-                    };
-                    n_steps++; n_step_lanes += n_box;
-                    if (want_box) box_step();
-#pragma unroll
-                    for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {
-                        const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
-                        n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
-                        if (more) box_step();
-                    }
-                }
-                if (few) break;
-                n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(act && tv_have_leaf));
-                if (act && tv_have_leaf) {
-                    T t; uint32_t prim;
-                    if (!near_first) {
-                        const DBvhNode<T> lf = fetch_node(P, tv_node);
-                        if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; }
-                        tv_node = lf.skip;
-                    } else if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, ray, t_min, tv_closest, t, prim) &&
-                        bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
-                    tv_have_leaf = false;
-                }
-            }
-            if (act && !tv_have_leaf && tv_node == BVH_DONE) {
-                if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
-                my_oi++;
-                phase = PH_OBJ;
-                if (my_oi < P.n_objects) {             // more objects follow: the world-space ray again (the time never changed)
-                    const WfPath<T>* src = W.in + slot;
-                    ray.o = mk<T>(src->o[0], src->o[1], src->o[2]);
-                    ray.d = mk<T>(src->d[0], src->d[1], src->d[2]);
-                }
-            }
-            DIAG_ADD(0);
-            continue;
-        }
-
-        // ================= hand-over pass
-        n_iters++;
-        n_active += (unsigned long long)__popcll(__ballot(phase == PH_OBJ || phase == PH_NEW));
-        // ---- finished searches go back to the pool
-        if (phase == PH_OBJ && my_oi >= P.n_objects) {
-            WfPath<T>* dst = W.in + slot;                     // (t, object, primitive) share one 16-byte piece of the record
-            dst->hit_t = closest; dst->hit_obj = any_hit ? id.obj : WF_NO_HIT; dst->hit_prim = id.prim;
-            if (FEATS & F_MEDIUM) { dst->rng[0] = rng.s0; dst->rng[1] = rng.s1; dst->rng[2] = rng.s2; dst->rng[3] = rng.s3; }
-            slot = NONE; phase = PH_NEW;
-        }
-        // ---- idle lanes take the next live paths of the wave's batch
-        for (;;) {
-            const unsigned long long want = __ballot(phase == PH_NEW);
-            if (want == 0ull) break;
-            if (q_count == 0u) {
-                if (list_done) break;
-                const unsigned long long base64 = (unsigned long long)next_batch * 64ull;
-                if (base64 >= (unsigned long long)W.n_alive) { list_done = true; break; }
-                const uint32_t base = (uint32_t)base64;
-                next_batch += n_waves_grid;
-                q_count = W.n_alive - base < 64u ? W.n_alive - base : 64u;
-                q_head = 0;
-                batch_slot = lane < q_count ? base + lane : NONE;           // the pool is compact: positions [0, n_alive) are the live paths
-            }
-            const uint32_t n_want = (uint32_t)__popcll(want);
-            const uint32_t take = n_want < q_count ? n_want : q_count;
-            const uint32_t rank = lane_rank(want);
-            const uint32_t got = (uint32_t)__shfl((int)batch_slot, (int)((q_head + rank) & 63u), 64);
-            if (phase == PH_NEW && rank < take) {
-                slot = got;
-                const WfPath<T>* src = W.in + slot;
-                ray.o = mk<T>(src->o[0], src->o[1], src->o[2]);
-                ray.d = mk<T>(src->d[0], src->d[1], src->d[2]);
-                ray.tm = src->tm;
-                if (FEATS & F_MEDIUM) { rng.s0 = src->rng[0]; rng.s1 = src->rng[1]; rng.s2 = src->rng[2]; rng.s3 = src->rng[3]; }
-                phase = PH_OBJ; my_oi = 0; closest = Lim<T>::inf(); any_hit = false;
-            }
-            q_head += take; q_count -= take;
-        }
-        // ---- world.hit (main.rs:48), resumable: objects in push order from my_oi up to the next BVH object or the end
-        for (uint32_t oi = 0; oi < P.n_objects; oi++) {
-            const bool here = phase == PH_OBJ && my_oi == oi;
-            if (__ballot(here) == 0) continue;
-            const DObject ob = ld_obj(P.objects + oi);
-            if (here) {
-                if (ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0)) {
-                    phase = PH_BVH; tv_node = ob.geom_first; tv_sp = 0; tv_closest = closest; tv_any = false; tv_best = 0; tv_have_leaf = false;
-                    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), ray);
-                    inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
-                } else {
-                    object_hit<T, FEATS>(P, oi, ob, ray, TMin<T>::v(), rng, closest, id, any_hit, stack);
-                    my_oi = oi + 1u;
-                }
-            }
-        }
-        DIAG_ADD(1);
-    }
-    if (P.stats) {
-        unsigned long long* const st = stats_row(P.stats);
-        const unsigned long long b = n_step_lanes;
-        if (lane == 0) { atomicAdd(&st[1], n_iters); atomicAdd(&st[2], n_active); atomicAdd(&st[9], n_steps); atomicAdd(&st[10], b); }
-#ifdef RT_DIAG
-        if (lane == 0) for (int q = 0; q < 2; q++) atomicAdd(&st[3 + q], dg_sum[q]);
-#endif
-    }
-}
-
-// Hit record + material for every live path (main.rs:50-118), one thread each; `P.out` receives the radiance of finished paths.
-template <typename T, uint32_t FEATS>
-__global__ void __launch_bounds__(1024) wf_shade_kernel(const KParams<T> P, const WfParams<T> W) {
-    __shared__ uint32_t wave_live[16], wave_base[16];
-    const uint32_t i = blockIdx.x * 1024u + threadIdx.x, lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    const bool valid = i < W.n_alive;
-    uint32_t lp = 0, smp = 0;
-    bool done = false;
-    V3<T> L = mk<T>(T(0), T(0), T(0));
-    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
-    V3<T> beta = mk<T>(T(0), T(0), T(0));
-    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    uint32_t depth_left = 0;
-    if (valid) {
-        const WfPath<T> rec_in = wf_load(W.in + i);
-        ray.o = mk<T>(rec_in.o[0], rec_in.o[1], rec_in.o[2]);
-        ray.d = mk<T>(rec_in.d[0], rec_in.d[1], rec_in.d[2]);
-        ray.tm = rec_in.tm;
-        beta = mk<T>(rec_in.beta[0], rec_in.beta[1], rec_in.beta[2]);
-        rng.s0 = rec_in.rng[0]; rng.s1 = rec_in.rng[1]; rng.s2 = rec_in.rng[2]; rng.s3 = rec_in.rng[3];
-        depth_left = rec_in.depth;
-        lp = rec_in.px; smp = rec_in.smp;
-        V3<T> e = mk<T>(T(0), T(0), T(0));
-        if (depth_left == 0u) {
-            done = true;                                                            // main.rs:42-45 (max_depth 0)
-        } else {
-            HitId id; id.obj = rec_in.hit_obj; id.prim = rec_in.hit_prim;
-            if (id.obj == WF_NO_HIT) { e = ld3(P.background); done = true; }         // main.rs:118
-            else {
-                Rec<T> rec;
-                finalize_hit<T, FEATS>(P, ray, rec_in.hit_t, id, true, rec);
-                shade_hit<T, FEATS>(P, rec, ray, beta, rng, depth_left, done, e);
-            }
-        }
-        if (done) L = beta * e;
-    }
-    // ---- survivors move to the OTHER pool, packed: the workgroup's survivors take consecutive positions (ONE atomic per workgroup
-    //      of 1024 paths: a single counter takes ~88 atomics per microsecond), so that the next round reads and writes the pool coalesced
-    const bool fin = valid && done, live = valid && !done;
-    {
-        const unsigned long long ml = __ballot(live);
-        if (lane == 0) wave_live[wave_in_block] = (uint32_t)__popcll(ml);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (uint32_t k = 0; k < 16u; k++) { wave_base[k] = tot; tot += wave_live[k]; }
-            const uint32_t b = tot ? atomicAdd(W.counters + 1, tot) : 0u;
-            for (uint32_t k = 0; k < 16u; k++) wave_base[k] += b;
-        }
-        __syncthreads();
-        const uint32_t bl = wave_base[wave_in_block];
-        if (live) {
-            const uint32_t o = bl + lane_rank(ml);
-            WfPath<T> r;
-            r.o[0] = ray.o.x; r.o[1] = ray.o.y; r.o[2] = ray.o.z; r.d[0] = ray.d.x; r.d[1] = ray.d.y; r.d[2] = ray.d.z; r.tm = ray.tm;
-            r.beta[0] = beta.x; r.beta[1] = beta.y; r.beta[2] = beta.z; r.hit_t = T(0);
-            r.rng[0] = rng.s0; r.rng[1] = rng.s1; r.rng[2] = rng.s2; r.rng[3] = rng.s3;
-            r.hit_obj = WF_NO_HIT; r.hit_prim = 0; r.px = lp; r.smp = smp; r.depth = depth_left;
-            wf_store(W.out + o, r);
-        }
-    }
-    // ---- finished paths hand in beta * e: lanes of the wave that share a pixel are summed first (fixed butterfly), one lane adds
-    double l0 = (double)L.x, l1 = (double)L.y, l2 = (double)L.z;
-    if (fin) {
-        if (!(l0 - l0 == 0.0 && l1 - l1 == 0.0 && l2 - l2 == 0.0)) atomicAdd(&P.stats[0], 1ull);
-        if (P.samples_out) { double* so = P.samples_out + ((size_t)lp * P.spp + smp) * 3u; so[0] = l0; so[1] = l1; so[2] = l2; }
-    }
-    unsigned long long m = __ballot(fin);
-    bool need = fin;
-    while (m) {
-        const uint32_t leader = (uint32_t)__builtin_ctzll(m);
-        const uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)lp, (int)leader);
-        const bool mine = need && lp == px;
-        const double s0 = wave_sum(mine ? l0 : 0.0), s1 = wave_sum(mine ? l1 : 0.0), s2 = wave_sum(mine ? l2 : 0.0);
-        if (lane == leader) { double* o = P.out + (size_t)px * 3u; unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2); }
-        need = need && !mine;
-        m = __ballot(need);
-    }
-}
-
-#if !defined(RT_KRES_ONLY)
-template <typename T> hipError_t launch_wf_gen(const KParams<T>& P, const WfParams<T>& W, hipStream_t stream) {
-    if (W.n_new == 0u) return hipSuccess;
-    hipLaunchKernelGGL((wf_gen_kernel<T>), dim3((W.n_new + 255u) / 256u), dim3(256), 0, stream, P, W);
-    return hipGetLastError();
-}
-template <typename T> hipError_t launch_wf_trace(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
-    return dispatch<T>(scene_feats, P.flags & ~16u, [&]() { return hipErrorInvalidValue; },          // (list scenes have no wavefront form)
-        [&](auto feats) {
-            constexpr uint32_t F = decltype(feats)::value;
-            hipError_t e = shmem > 65536u ? hipFuncSetAttribute((const void*)wf_trace_kernel<T, F>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) : hipSuccess;
-            if (e != hipSuccess) return e;
-            hipLaunchKernelGGL((wf_trace_kernel<T, F>), dim3(n_blocks), dim3(Shape<F>::THREADS), shmem, stream, P, W);
-            return hipGetLastError();
-        });
-}
-template <typename T> hipError_t launch_wf_shade(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, hipStream_t stream) {
-    if (W.n_alive == 0u) return hipSuccess;
-    return dispatch<T>(scene_feats, P.flags & ~16u, [&]() { return hipErrorInvalidValue; },
-        [&](auto feats) {
-            hipLaunchKernelGGL((wf_shade_kernel<T, decltype(feats)::value>), dim3((W.n_alive + 1023u) / 1024u), dim3(1024), 0, stream, P, W);
-            return hipGetLastError();
-        });
-}
-template hipError_t launch_wf_gen<double>(const KParams<double>&, const WfParams<double>&, hipStream_t);
-template hipError_t launch_wf_gen<float>(const KParams<float>&, const WfParams<float>&, hipStream_t);
-template hipError_t launch_wf_trace<double>(const KParams<double>&, const WfParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);
-template hipError_t launch_wf_trace<float>(const KParams<float>&, const WfParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);
-template hipError_t launch_wf_shade<double>(const KParams<double>&, const WfParams<double>&, uint32_t, hipStream_t);
-template hipError_t launch_wf_shade<float>(const KParams<float>&, const WfParams<float>&, uint32_t, hipStream_t);
-#endif
 #endif
 
 } // namespace rt

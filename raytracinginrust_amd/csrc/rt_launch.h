@@ -6,12 +6,12 @@
 namespace rt {
 // Shape of the instantiation that serves a scene: workgroup size, entries of each wave's camera-path queue (80 B each), and whether
 // it runs as ONE workgroup per CU (BVH kernels: the CU's LDS then holds one copy of the top of the BVH, KParams::n_cached nodes).
-struct LaunchShape { uint32_t threads, queue_entries; bool one_per_cu, acc_in_lds; };
+struct LaunchShape { uint32_t threads, queue_entries; bool one_per_cu; };
 LaunchShape pathtrace_shape(uint32_t scene_feats, uint32_t flags);
-// Dynamic LDS of one workgroup: [n_cached nodes][waves x queue][waves x stack_depth x 64 dwords][waves x 3 x 64 f64 partial sums]
+// Dynamic LDS of one workgroup: [n_cached nodes][waves x queue][waves x stack_depth x 64 dwords]
 inline size_t pathtrace_lds_bytes(const LaunchShape& g, uint32_t stack_depth, uint32_t n_cached, size_t node_bytes) {
     const size_t waves = g.threads / 64u;
-    return (size_t)n_cached * node_bytes + waves * ((size_t)g.queue_entries * 80u + (size_t)stack_depth * 64u * sizeof(uint32_t) + (g.acc_in_lds ? 3u * 64u * 8u : 0u));
+    return (size_t)n_cached * node_bytes + waves * ((size_t)g.queue_entries * 80u + (size_t)stack_depth * 64u * sizeof(uint32_t));
 }
 // Counter block the kernel reports into: RT_STATS_ROWS copies (row = block index mod rows) of RT_STATS_SLOTS 64-bit counters
 static const uint32_t RT_STATS_SLOTS = 16u, RT_STATS_ROWS = 32u;
@@ -20,8 +20,4 @@ static const size_t RT_STATS_BYTES = (size_t)RT_STATS_SLOTS * RT_STATS_ROWS * si
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
 // Resident blocks per CU for the instantiation that serves `scene_feats`.
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem);
-// Wavefront backend (BVH scenes, RT_WAVEFRONT): one round = gen, trace, shade (rt_kernel.hip)
-template <typename T> hipError_t launch_wf_gen(const KParams<T>& P, const WfParams<T>& W, hipStream_t stream);
-template <typename T> hipError_t launch_wf_trace(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
-template <typename T> hipError_t launch_wf_shade(const KParams<T>& P, const WfParams<T>& W, uint32_t scene_feats, hipStream_t stream);
 }

@@ -155,7 +155,6 @@ bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint3
     if (const char* v = std::getenv("RT_MULTI_FAIL_RANK")) fail_rank = std::strtol(v, nullptr, 10);
     if (virtual_ranks) devs.assign(virtual_ranks, devs[0]);
     const uint32_t N = (uint32_t)devs.size();
-    if ((flags & RT_WAVEFRONT) && N > 1) { err = "RT_WAVEFRONT is a synchronous single-device measurement backend: not available in rt_render_multi with more than one rank"; return false; }
     if (!rt::flatten_for_render(s)) { err = rt_last_error(); return false; }
     if (W < 2 || H < 2 || spp == 0 || (uint64_t)W * H > 0x7FFFFFFFull) {      // rt_render_device repeats these with its own messages
         err = "bad frame: W and H must be >= 2, samples_per_pixel >= 1, W*H <= 2^31 - 1"; return false;

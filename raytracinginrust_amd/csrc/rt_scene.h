@@ -34,14 +34,13 @@ struct HostFlat {             // canonical f64 flattening
     std::vector<DLight> lights;
     uint32_t feats = 0;
     uint32_t bvh_depth = 0;
-    uint32_t n_defer_rings = 0;    // bare (non-medium) BVH objects in the world list; each has DObject::pad0 = its index among them
     bool bvh_tame = true;          // all BVH boxes finite, |.| < 1e300 (1e30 matters for the f32 variant: checked there too), min <= max
 };
 
 template <typename T> struct DeviceScene {   // device copies of HostFlat for one arithmetic type
     bool valid = false;
     void* objects = nullptr; void* ops = nullptr; void* rects = nullptr; void* spheres = nullptr; void* mspheres = nullptr;
-    void* tris = nullptr; void* bvh = nullptr; void* bvh_soa = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
+    void* tris = nullptr; void* bvh = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
     void* lights = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr;
 };
 
@@ -67,7 +66,6 @@ struct Scene {
     static const int N_SLOTS = 4;
     struct LaunchSlot {
         void* d_queue = nullptr; void* d_stats = nullptr;
-        void* d_defer = nullptr; size_t defer_bytes = 0;       // deferred-BVH-entry kernels: the wavefronts' rings of parked paths
         void* ev_start = nullptr; void* ev_stop = nullptr;
         void* stream = nullptr; bool recorded = false, timed = true; unsigned long long seq = 0;
     };
@@ -83,7 +81,6 @@ struct Scene {
         void* d_tiles = nullptr; size_t tiles_bytes = 0;
         void* d_gather = nullptr; size_t gather_bytes = 0;
         void* d_frame = nullptr; size_t frame_bytes = 0;
-        void* d_wf = nullptr; size_t wf_bytes = 0;                            // wavefront backend: the two path pools (RT_WAVEFRONT)
     };
     std::vector<DeviceCtx*> ctxs;          // created on first use of a device
     int last_device = -1;                  // device of the most recent launch (what rt_last_* report)

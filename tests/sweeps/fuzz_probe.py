@@ -1,8 +1,8 @@
 """Details of the samples in which the GPU and the CPU oracle disagree for one random scene of tests/test_fuzz_gpu.py, and for the first of
 them the hits of the path level by level on both sides (the kernel's from a -DRT_TRACE_PATH build: tools/mkab.sh trace "-DRT_TRACE_PATH"
-"-DRT_TRACE_PATH"; uses the oracle: a developer probe, run by hand).   usage: python tools/fuzz_probe.py seed [seed ...]"""
+"-DRT_TRACE_PATH"; uses the oracle: a developer probe, run by hand).   usage: python tests/sweeps/fuzz_probe.py seed [seed ...]"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 os.environ.setdefault('RT_AMD_LIB', os.path.join(ROOT, 'raytracinginrust_amd/csrc/ab/trace.so'))
 import numpy as np
 import torch

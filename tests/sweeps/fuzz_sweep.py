@@ -39,8 +39,7 @@ for seed in range(first, first + nm):
     _, lock = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
     _, pers = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_PERSISTENT_BVH, want_samples=True)
     bad_bits += int((lock.view(np.uint64) != pers.view(np.uint64)).sum())
-    os.environ["RT_DEFER_DENSE"] = ("48", "65", "20")[seed % 3]; os.environ["RT_DEFER_STOP"] = ("20", "40", "1")[seed % 3]      # round 3: the deferred-entry loop
-    _, defr = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_DEFER_BVH, want_samples=True)
+    _, defr = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_LOCKSTEP_BVH | R.RT_COOP_BVH, want_samples=True)      # round 4: the lane-cooperative walk
     bad_defer += int((lock.view(np.uint64) != defr.view(np.uint64)).sum())
     ob, ocam, obg = _mesh_room(obe, seed)
     _, ref = orc.render(ob, ocam, obg, W, H, spp, 16, seed=5 + seed, want_samples=True)
@@ -48,4 +47,4 @@ for seed in range(first, first + nm):
     d = np.abs(np.where(fin, pers, 0.0) - np.where(fin, ref, 0.0))
     bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, ref, 0.0)))).any(axis=-1)
     div_m += int(bad.sum()); worst_m = max(worst_m, float(d[~bad].max()))
-print(f'mesh rooms {first}..{first + nm - 1}: persistent vs lock-step differing words {bad_bits}; deferred entry vs lock-step differing words {bad_defer}; vs oracle {div_m} diverged samples, worst of the rest {worst_m:.3e}')
+print(f'mesh rooms {first}..{first + nm - 1}: persistent vs lock-step differing words {bad_bits}; cooperative walk vs lock-step differing words {bad_defer}; vs oracle {div_m} diverged samples, worst of the rest {worst_m:.3e}')

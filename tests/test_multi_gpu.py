@@ -99,8 +99,6 @@ def test_render_multi_failure_leaves_nothing_behind(pbe, monkeypatch):
     monkeypatch.delenv("RT_MULTI_FAIL_RANK")
     again = R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
     assert np.array_equal(again, good) and np.all(np.abs(again - ref) <= 1e-12 * (spp + np.abs(ref)))
-    with pytest.raises(R.RenderError, match="RT_WAVEFRONT"):
-        R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1, flags=R.RT_WAVEFRONT)
 
 
 @pytest.mark.gpu

@@ -727,80 +727,6 @@ def test_aabb_hit_on_the_device_against_the_oracle(pbe, obe):
     assert np.array_equal((out[use] >> 1) & 1, ref[use]), "the NaN-free form disagrees where it would be used"
 
 
-@pytest.mark.parametrize("name", ["random", "final", "teapot", "smoke"])
-def test_wavefront_backend_is_scheduling_only(name, pbe, earth, monkeypatch):
-    """RT_WAVEFRONT (opt-in, BVH scenes): the frame's paths go through a pool in HBM in rounds of three kernels (new camera paths /
-    world.hit with lanes that fetch the next path when their search ends / hit record + material) instead of one persistent kernel.
-    Per path the operations and their order are the megakernel's: every sample is bit-identical, the per-pixel sums differ only by the
-    order of the additions.  A small pool forces many rounds; list scenes ignore the flag."""
-    if name == "smoke":
-        b, cam, bg = scenes.cornell_box_with_smoke(pbe)         # media with box boundaries beside a list: no BVH -> flag ignored
-    else:
-        b, cam, bg = build_scene(name, pbe, earth)
-    W, H, spp, depth = 72, 40, 8, 30
-    ref, rs = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
-    n_bad = R.last_stats(b)["nonfinite_samples"]
-    for pool in ("16777216", "1000"):
-        monkeypatch.setenv("RT_WF_POOL", pool)
-        got, gs = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_WAVEFRONT, want_samples=True)
-        assert np.array_equal(rs.view(np.uint64), gs.view(np.uint64))
-        assert R.last_stats(b)["nonfinite_samples"] == n_bad
-        fin = np.isfinite(ref)
-        assert np.array_equal(fin, np.isfinite(got)) and np.all(np.abs(got[fin] - ref[fin]) <= 1e-12 * (spp + np.abs(ref[fin])))
-    monkeypatch.delenv("RT_WF_POOL")
-    # sharded as on 3 GPUs: each rank's tiles through the wavefront backend equal the megakernel's
-    import torch
-    for rank in range(3):
-        a = D.TileRenderer(b, cam, bg, W, H, spp, depth, tile_px=64, rank=rank, world=3).render_local().clone()
-        c = D.TileRenderer(b, cam, bg, W, H, spp, depth, flags=R.RT_WAVEFRONT, tile_px=64, rank=rank, world=3).render_local().clone()
-        torch.cuda.synchronize()
-        assert torch.allclose(a, c, rtol=1e-12, atol=1e-12 * spp, equal_nan=True)
-
-
-@pytest.mark.parametrize("name", ["final", "teapot", "mesh0", "mesh1", "random", "smoke"])
-def test_deferred_bvh_entry_is_scheduling_only(name, pbe, obe, orc_mod, earth, monkeypatch):
-    """RT_DEFER_BVH: lanes whose rays enter a BVH object that few lanes of their wavefront enter park their paths in a per-wave ring in
-    device memory; once 64 wait, the wavefront walks the tree for all of them (rt_kernel.hip: trace_deferred).  A path's own operations
-    and their order are the lock-step loop's: every sample is bit-identical to it (and matches the oracle); per-pixel sums differ only by
-    the order of the additions.  Thresholds from "always park" (65) to "never park" (0), and walks suspended early, late or never, give the same samples; scenes whose BVH is the
-    whole world (random) or that have none (smoke) ignore the flag."""
-    if name == "smoke":
-        mk = lambda be: scenes.cornell_box_with_smoke(be)
-    elif name.startswith("mesh"):
-        mk = lambda be: _mesh_room(be, int(name[4:]))
-    else:
-        mk = lambda be: build_scene(name, be, earth)
-    b, cam, bg = mk(pbe)
-    W, H, spp, depth = 96, 54, 8, 30
-    ref, rs = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_DEFER_BVH, want_samples=True)
-    n_bad = R.last_stats(b)["nonfinite_samples"]
-    for below, stop in (("48", "20"), ("65", "64"), ("0", "20"), ("7", "1"), ("65", "33"), ("30", "12")):
-        monkeypatch.setenv("RT_DEFER_DENSE", below)        # walked on the spot when at least this many lanes enter (0: always, 65: never)
-        monkeypatch.setenv("RT_DEFER_STOP", stop)          # a walk is suspended once fewer lanes than this are still in it (1: never)
-        got, gs = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_DEFER_BVH, want_samples=True)
-        assert np.array_equal(rs.view(np.uint64), gs.view(np.uint64)), below
-        assert R.last_stats(b)["nonfinite_samples"] == n_bad
-        fin = np.isfinite(ref)
-        assert np.array_equal(fin, np.isfinite(got)) and np.all(np.abs(got[fin] - ref[fin]) <= 1e-12 * (spp + np.abs(ref[fin])))
-        walks = R.last_traversal_stats(b)["traversal_steps"]
-        if name in ("final", "teapot", "mesh0", "mesh1") and below != "0":
-            assert walks > 0                      # paths were parked and walked 64 at a time
-        if name in ("random", "smoke") or below == "0":
-            assert walks == 0
-    monkeypatch.delenv("RT_DEFER_DENSE"); monkeypatch.delenv("RT_DEFER_STOP")
-    ob, ocam, obg = mk(obe)
-    _, os_ = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
-    n_div, _, _ = _compare_samples(gs, os_)
-    assert n_div <= MAX_DIVERGED
-    # sharded as on 3 GPUs: each rank's tiles equal the lock-step loop's
-    import torch
-    for rank in range(3):
-        a = D.TileRenderer(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_DEFER_BVH, tile_px=64, rank=rank, world=3).render_local().clone()
-        c = D.TileRenderer(b, cam, bg, W, H, spp, depth, flags=R.RT_DEFER_BVH, tile_px=64, rank=rank, world=3).render_local().clone()
-        torch.cuda.synchronize()
-        assert torch.allclose(a, c, rtol=1e-12, atol=1e-12 * spp, equal_nan=True)
-
-
 @pytest.mark.parametrize("name", ["random", "final", "mesh0", "teapot"])
 def test_speculative_box_steps_are_scheduling_only(name, pbe, obe, orc_mod, earth):
     """RT_SPECULATE_BVH: in the lock-step BVH walk a lane that has reached a leaf walks on along the leaf's skip link while it waits for
@@ -811,7 +737,7 @@ def test_speculative_box_steps_are_scheduling_only(name, pbe, obe, orc_mod, eart
     mk = (lambda be: _mesh_room(be, 0)) if name == "mesh0" else (lambda be: build_scene(name, be, earth))
     b, cam, bg = mk(pbe)
     W, H, spp, depth = 96, 54, 8, 30
-    _, plain = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH | R.RT_NO_DEFER_BVH, want_samples=True)
+    _, plain = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH, want_samples=True)
     _, spec = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_SPECULATE_BVH, want_samples=True)
     assert np.array_equal(plain.view(np.uint64), spec.view(np.uint64))
     _, auto = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)

@@ -12,7 +12,7 @@ spp = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 for key in os.environ.get('RT_WORKLOADS', 'C3').split(','):
     w = workloads.WORKLOADS[key]
     b, cam, bg = workloads.build(w, be, earth)
-    R.render(b, cam, bg, w.W, w.H, min(spp, w.spp), w.max_depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_DEFER_BVH)
+    R.render(b, cam, bg, w.W, w.H, min(spp, w.spp), w.max_depth, flags=R.RT_LOCKSTEP_BVH)
     ms = R.last_kernel_ms(b)
     cyc = (C.c_ulonglong * 8)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]; be.lib.rt_debug_section_cycles(b.h, cyc)
     leaf = (C.c_ulonglong * 2)(); be.lib.rt_last_leaf_steps(b.h, leaf)
