@@ -137,7 +137,7 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
     roof = {"bound": "f64_valu", "achieved": achieved, "peak": peak, "unit": "Tops/s (f64 VALU issue-equivalents: lane-operations weighted by issue cost)",
             "frac": achieved / peak,
             "traffic": None, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, KB counters x 1024; raw values)",
-            "traffic_source": None,
+            "traffic_source": None, "hbm_measured_GBps": None, "hbm_measured_frac": None,
             "ops_per_sample": ops, "flops_per_sample_unweighted": workloads.flops(per_kind),
             "achieved_unweighted_TFLOPs": workloads.flops(per_kind) * local_samples / (k_ms * 1e-3) / 1e12,
             "ops_per_sample_source": "raytracinginrust_amd/workloads.py F64_OPS_PER_SAMPLE x VALU_OP_WEIGHTS (the reference's f64 operations by kind, counted by "
@@ -160,6 +160,9 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
         else:
             if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
                 roof["traffic"] = (vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                # north_star's literal: HBM GB/s against the chip's peak — the replayed counter bytes over THIS run's kernel time
+                roof["hbm_measured_GBps"] = roof["traffic"] / (k_ms * 1e-3) / 1e9
+                roof["hbm_measured_frac"] = roof["hbm_measured_GBps"] / HBM_PEAK_GBPS
                 roof["traffic_source"] = f"profiles/{src}: committed rocprofv3 --pmc passes of this command on this build (not measured in this run)"
             need = ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_THREAD_CYCLES_VALU")
             waves = vals.get("LAUNCH_WAVES", vals.get("SQ_WAVES"))      # grid size / 64 (SQ_WAVES reports double on some dispatches)
@@ -313,7 +316,7 @@ def main():
         k_total_ms, k_launches = R.kernel_time_total(b)
         assert k_launches == steps
         res = {"w": w, "elapsed": elapsed, "steps": steps, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
-               "pipeline": tr.pipeline, "multi_ms": None}
+               "pipeline": tr.pipeline, "multi_ms": None, "stats_scope": "rank 0's share" if world > 1 else "frame"}
         if rank == 0:
             assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
             res["mean_radiance"] = float(torch.nan_to_num(frame).mean().item()) / w.spp
@@ -346,7 +349,8 @@ def main():
         frame = R.multi_frame(b, w.W, w.H)
         res = {"w": w, "elapsed": elapsed, "steps": steps, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
                "pipeline": 1, "multi_ms": R.last_multi_ms(b), "mean_radiance": float(np.nan_to_num(frame).mean()) / w.spp,
-               "local_samples": w.samples // n_gpus}           # mean over the N launches of a frame
+               "local_samples": w.samples / n_gpus,            # per launch: k_ms is the mean over the frame's N launches, so is this
+               "stats_scope": "frame"}                         # rt_last_stats sums the counters of the frame's N launches
         del b
         torch.cuda.empty_cache()
         return res
@@ -380,11 +384,14 @@ def main():
             others[we.key] = {"workload": we.describe(), "value": we.samples * r["steps"] / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": r["steps"],
                               "warmup": f"1 frame at {max(1, we.spp // 32)} spp (same kernel and scene)", "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
                               "kernel_ms": r["k_ms"], "frac": ro["frac"], "ops_per_sample": ro["ops_per_sample"], "achieved_Tops": ro["achieved"],
-                              "model_hbm_ratio": ro["model_hbm"]["ratio"], "bytes_per_sample": ro["model_hbm"]["bytes_per_sample"],
+                              "model_hbm_ratio": ro["model_hbm"]["ratio"], "exceeds_hbm_peak": ro["model_hbm"]["exceeds_hbm_peak"],
+                              "hbm_measured_GBps": ro["hbm_measured_GBps"], "hbm_measured_frac": ro["hbm_measured_frac"],
+                              "bytes_per_sample": ro["model_hbm"]["bytes_per_sample"],
                               "model_hbm_GBps": ro["model_hbm"]["achieved_GBps"], "traffic": ro["traffic"], "traffic_source": ro["traffic_source"],
                               "valu_pmc": va, "kernel": ro["kernel"], "multi_ms": r["multi_ms"],
                               "lane_utilisation": r["stats"]["live_lane_iterations"] / max(1, 64 * r["stats"]["wave_iterations"]),
-                              "nonfinite_samples_rank0": r["stats"]["nonfinite_samples"], "mean_radiance": r["mean_radiance"]}
+                              "nonfinite_samples": r["stats"]["nonfinite_samples"], "nonfinite_samples_scope": r["stats_scope"],
+                              "mean_radiance": r["mean_radiance"]}
         if inproc:
             par = (f"one process, rt_render_multi_device: {n_gpus} " + ("VIRTUAL ranks on one device (RT_MULTI_VIRTUAL_RANKS test hook: the decomposition, "
                    "not a measurement; device-to-device copies stand in for the gather)" if virtual else "GPUs, ncclCommInitAll + 1 ncclGather + un-permute on device 0"))
@@ -400,8 +407,11 @@ def main():
                        "frames_in_flight": main_res["pipeline"]},
             "roofline": roof, "valu_pmc": valu, "cpu_baseline": cpu, "workloads": others,
             "lane_utilisation": st["live_lane_iterations"] / max(1, 64 * st["wave_iterations"]),
-            "nonfinite_samples_rank0": st["nonfinite_samples"], "mean_radiance": main_res["mean_radiance"],
+            "nonfinite_samples": st["nonfinite_samples"], "nonfinite_samples_scope": main_res["stats_scope"], "mean_radiance": main_res["mean_radiance"],
         }
+        if inproc:
+            out["config"]["frames_consumed"] = ("no: every step's frame stays in device 0's memory (two buffers, alternating), only the last one is read "
+                                                "back after the timed region — as the N = 1 bench leaves its frames in HBM")
         if len(tried) > 1:
             out["pipeline_tried"] = {str(pl): {"ms_per_step": r["elapsed"] / args.steps * 1e3, "value": w.samples * args.steps / r["elapsed"] / 1e6}
                                      for pl, r in tried.items()}

@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 from .api import Backend, CameraParams, c_double_p, c_u32_p
 
@@ -34,10 +35,15 @@ def load_path(path: str) -> Backend:
         raise LibraryMissing(
             f"{path} is missing: build it with `make -C raytracinginrust_amd/csrc` "
             "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no fallback path.")
-    try:                # PyTorch first, when it is there: it brings its own copy of the HIP runtime, and a process in which this library's copy was
-        import torch    # loaded before it leaves torch without a device ("No HIP GPUs are available") — dist.py and bench.py need both
-    except ImportError: # noqa: F401
-        pass
+    # PyTorch first, when this process is going to use it: torch brings its own copy of the HIP runtime, and a process in which this
+    # library's copy was loaded before it leaves torch without a device ("No HIP GPUs are available").  dist.py and bench.py need both,
+    # so the preload is the default wherever torch is installed; RT_AMD_NO_TORCH_PRELOAD=1 skips it (a host that never imports torch
+    # saves the import), and a torch that is present but broken must not make the renderer unloadable.
+    if "torch" not in sys.modules and not os.environ.get("RT_AMD_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except Exception:       # ImportError, OSError (a missing .so), RuntimeError (version mismatch): the renderer does not need torch
+            pass
     lib = C.CDLL(path)
     be = Backend(lib, "rt_")
     cam_p = C.POINTER(CameraParams)

@@ -73,7 +73,7 @@ void rt_scene_destroy(rt_scene* sc) {
             if (l.ev_start) (void)hipEventDestroy((hipEvent_t)l.ev_start);
             if (l.ev_stop) (void)hipEventDestroy((hipEvent_t)l.ev_stop);
         }
-        free_dev(c->d_tiles); free_dev(c->d_gather); free_dev(c->d_frame);
+        free_dev(c->d_tiles); free_dev(c->d_gather); free_dev(c->d_frame[0]); free_dev(c->d_frame[1]);
         if (c->stream) (void)hipStreamDestroy((hipStream_t)c->stream);
         delete c;
     }
@@ -435,7 +435,13 @@ static int current_ctx(Scene& s, Scene::DeviceCtx** out) {
     return 0;
 }
 
-// A finished launch's kernel time joins the running total exactly once (rt_kernel_time_total).
+// Events and counter blocks belong to one device: waits, elapsed times and copies run with that device current.
+struct DeviceGuard {
+    int prev = -1; bool switched = false;
+    explicit DeviceGuard(int device) { if (hipGetDevice(&prev) == hipSuccess && prev != device) switched = hipSetDevice(device) == hipSuccess; }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+// A finished launch's kernel time joins the running total exactly once (rt_kernel_time_total).  Current device: the slot's.
 static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
     if (!l.recorded || l.timed) return 0;
     HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
@@ -443,6 +449,20 @@ static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
     HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
     s.kernel_ms_total += ms; s.kernel_launches_timed++;
     l.timed = true;
+    return 0;
+}
+// A finished launch's counters join its frame's sums exactly once (Scene::acc_stats; rt_last_stats and friends report the whole frame,
+// also when it was N launches on N devices or N virtual ranks).  Counters of frames older than the one being summed are dropped.
+// Current device: the slot's.
+static int harvest_slot(Scene& s, Scene::LaunchSlot& l) {
+    if (!l.recorded || l.harvested) return 0;
+    l.harvested = true;
+    if (l.group < s.acc_group) return 0;
+    HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
+    unsigned long long raw[RT_STATS_ROWS * RT_STATS_SLOTS];
+    HIP_OK(hipMemcpy(raw, l.d_stats, sizeof(raw), hipMemcpyDeviceToHost));
+    if (l.group > s.acc_group) { s.acc_group = l.group; for (unsigned long long& x : s.acc_stats) x = 0; }
+    for (uint32_t k = 0; k < RT_STATS_SLOTS; k++) for (uint32_t r = 0; r < RT_STATS_ROWS; r++) s.acc_stats[k] += raw[r * RT_STATS_SLOTS + k];
     return 0;
 }
 // The launch slot for `stream`.  A stream alternates between (up to) two slots, so that the host can enqueue a frame's kernel while
@@ -458,6 +478,7 @@ static int acquire_slot(Scene& s, Scene::DeviceCtx& c, hipStream_t stream, Scene
     if (!pick && mine_lru) pick = mine_lru;
     if (!pick) { pick = &c.slots[0]; for (Scene::LaunchSlot& l : c.slots) if (l.seq < pick->seq) pick = &l; }
     if (settle_slot(s, *pick)) return -1;             // also waits for a launch that may still be running in this slot
+    if (pick->group == s.frame_group && harvest_slot(s, *pick)) return -1;      // an earlier share of the frame being enqueued (virtual ranks): keep its counters
     if (!pick->d_queue) HIP_OK(hipMalloc(&pick->d_queue, 64));
     if (!pick->d_stats) HIP_OK(hipMalloc(&pick->d_stats, RT_STATS_BYTES));
     if (!pick->ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); pick->ev_start = e; }
@@ -481,13 +502,19 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
         if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size()) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
+    // Lane-cooperative BVH walk (scheduling only, rt_kernel.hip: bvh_hit_coop): the reference-order lock-step kernels of scenes without the
+    // principled material
+    {
+        const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
+        if (!can || (flags & RT_NO_COOP_BVH)) out &= ~(uint32_t)RT_COOP_BVH;
+    }
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
     // enters it, which is where walking on past an untested leaf pays (*measured* random spheres +2.6 %; scenes whose trees few lanes
     // enter lose 3 %)
     {
         const bool one_bvh = f.objects.size() == 1 && f.objects[0].geom_kind == G_BVH && f.objects[0].medium < 0;
         const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u &&
-                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
+                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH | RT_COOP_BVH));
         if (can && one_bvh && !(flags & RT_NO_SPECULATE_BVH)) out |= RT_SPECULATE_BVH;
         if (!can || (flags & RT_NO_SPECULATE_BVH)) out &= ~(uint32_t)RT_SPECULATE_BVH;
     }
@@ -552,6 +579,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     uint64_t n_local_px = (uint64_t)P.n_local_tiles * tile_px;
     if (n_local_px >= 0xFFFFFFFFull) return set_err("too many local pixels");
     if ((size_t)n_local_px * 3 * sizeof(double) > d_out_bytes) return set_err("output buffer too small for n_local_tiles * tile_px * 3 doubles");
+    if (!s.group_open) s.frame_group++;              // a frame of its own (rt_render_multi numbers its N launches as one)
     Scene::LaunchSlot* slot = nullptr;
     if (acquire_slot(s, c, stream, &slot)) return -1;
     P.queue = (uint32_t*)slot->d_queue; P.stats = (unsigned long long*)slot->d_stats;
@@ -610,11 +638,14 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
 
     P.trace_out = nullptr; P.trace_px = 0u; P.trace_s = 0u;
     if (s.trace_px >= 0) {                          // debugging aid: 16 doubles per level of one path (written by -DRT_TRACE_PATH builds only)
+        if (world > 1) return set_err("rt_debug_trace_path: tracing a path is for unsharded renders (world = 1)");
         const size_t bytes = ((size_t)max_depth + 1u) * 16u * sizeof(double);
-        if (s.d_trace) { (void)hipFree(s.d_trace); s.d_trace = nullptr; }
-        HIP_OK(hipMalloc(&s.d_trace, bytes));
+        if (!s.d_trace || s.trace_device != c.device || s.trace_levels != max_depth + 1u) {      // one buffer per (device, depth): earlier launches keep a valid pointer
+            if (s.d_trace) { DeviceGuard guard(s.trace_device); (void)hipDeviceSynchronize(); (void)hipFree(s.d_trace); s.d_trace = nullptr; }
+            HIP_OK(hipMalloc(&s.d_trace, bytes));
+            s.trace_device = c.device; s.trace_levels = max_depth + 1u;
+        }
         HIP_OK(hipMemsetAsync(s.d_trace, 0, bytes, stream));
-        s.trace_device = c.device;
         P.trace_out = (double*)s.d_trace; P.trace_px = (uint32_t)s.trace_px; P.trace_s = (uint32_t)s.trace_s;
     }
     HIP_OK(hipMemsetAsync(slot->d_queue, 0, 64, stream));
@@ -623,7 +654,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     HIP_OK(hipEventRecord((hipEvent_t)slot->ev_start, stream));
     HIP_OK(launch_pathtrace<T>(P, f.feats, (uint32_t)n_blocks, shmem, stream));
     HIP_OK(hipEventRecord((hipEvent_t)slot->ev_stop, stream));
-    slot->recorded = true; slot->timed = false; slot->seq = ++s.launch_seq;
+    slot->recorded = true; slot->timed = false; slot->seq = ++s.launch_seq; slot->group = s.frame_group; slot->harvested = false;
     c.last_slot = (int)(slot - c.slots);
     s.last_device = c.device;
     s.launch_info[0] = (uint32_t)n_blocks; s.launch_info[1] = shape.threads; s.launch_info[2] = (uint32_t)shmem; s.launch_info[3] = P.n_cached;
@@ -698,6 +729,7 @@ bool flatten_for_render(Scene& s) { if (flatten_scene(s)) return true; set_err(s
 int device_kernel_ms(Scene& s, int device, float* ms) {
     for (Scene::DeviceCtx* c : s.ctxs) if (c->device == device && c->last_slot >= 0) {
         Scene::LaunchSlot& l = c->slots[c->last_slot];
+        DeviceGuard guard(c->device);
         HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
         HIP_OK(hipEventElapsedTime(ms, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
         return 0;
@@ -711,6 +743,7 @@ int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
     Scene::DeviceCtx* c = sc ? sc->s.last_ctx() : nullptr;
     if (!sc || !ms_out || !c || c->last_slot < 0) return set_err("no kernel has been launched for this scene");
     Scene::LaunchSlot& l = c->slots[c->last_slot];
+    DeviceGuard guard(c->device);
     HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
     HIP_OK(hipEventElapsedTime(ms_out, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
     return 0;
@@ -721,22 +754,25 @@ int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
 // for the launches still in flight.  For callers that keep several frames in flight and must not stop after each one.
 int rt_kernel_time_total(rt_scene* sc, double* ms_total, unsigned long long* n_launches, int reset) {
     if (!sc) return set_err("null argument");
-    for (Scene::DeviceCtx* c : sc->s.ctxs) for (Scene::LaunchSlot& l : c->slots) if (settle_slot(sc->s, l)) return -1;
+    for (Scene::DeviceCtx* c : sc->s.ctxs) { DeviceGuard guard(c->device); for (Scene::LaunchSlot& l : c->slots) if (settle_slot(sc->s, l)) return -1; }
     if (ms_total) *ms_total = sc->s.kernel_ms_total;
     if (n_launches) *n_launches = sc->s.kernel_launches_timed;
     if (reset) { sc->s.kernel_ms_total = 0.0; sc->s.kernel_launches_timed = 0; }
     return 0;
 }
 // The kernel spreads its end-of-launch counter atomics over RT_STATS_ROWS copies of the counter block (row = block index mod
-// rows): 4096 waves adding to one address serialise in the L2 atomic unit.  Readers sum the rows.
+// rows): 4096 waves adding to one address serialise in the L2 atomic unit.  Readers sum the rows — and the launches of the most
+// recent FRAME: one for rt_render / rt_render_device, one per device (or virtual rank) for rt_render_multi*.
 static int read_stats(rt_scene* sc, unsigned long long h[RT_STATS_SLOTS]) {
-    Scene::DeviceCtx* c = sc ? sc->s.last_ctx() : nullptr;
-    if (!sc || !c || c->last_slot < 0) return set_err("no kernel has been launched for this scene");
-    Scene::LaunchSlot& l = c->slots[c->last_slot];
-    HIP_OK(hipEventSynchronize((hipEvent_t)l.ev_stop));
-    unsigned long long raw[RT_STATS_ROWS * RT_STATS_SLOTS];
-    HIP_OK(hipMemcpy(raw, l.d_stats, sizeof(raw), hipMemcpyDeviceToHost));      // unified addressing: the pointer names its device
-    for (uint32_t k = 0; k < RT_STATS_SLOTS; k++) { h[k] = 0; for (uint32_t r = 0; r < RT_STATS_ROWS; r++) h[k] += raw[r * RT_STATS_SLOTS + k]; }
+    Scene::DeviceCtx* lc = sc ? sc->s.last_ctx() : nullptr;
+    if (!sc || !lc || lc->last_slot < 0) return set_err("no kernel has been launched for this scene");
+    Scene& s = sc->s;
+    const unsigned long long group = lc->slots[lc->last_slot].group;
+    for (Scene::DeviceCtx* c : s.ctxs) {
+        DeviceGuard guard(c->device);
+        for (Scene::LaunchSlot& l : c->slots) if (l.recorded && l.group == group && harvest_slot(s, l)) return -1;
+    }
+    for (uint32_t k = 0; k < RT_STATS_SLOTS; k++) h[k] = s.acc_group == group ? s.acc_stats[k] : 0ull;
     return 0;
 }
 // Geometry of the most recent launch: [0] workgroups, [1] threads per workgroup, [2] dynamic LDS bytes per workgroup, [3] BVH nodes
@@ -793,6 +829,8 @@ int rt_debug_trace_path(rt_scene* sc, long long local_pixel, long long sample) {
 int rt_debug_get_trace(rt_scene* sc, double* out, uint32_t n_levels) {
     if (!sc || !out) return set_err("null argument");
     if (!sc->s.d_trace) return set_err("no path has been traced (rt_debug_trace_path, then a render)");
+    if (n_levels > sc->s.trace_levels) return set_err("rt_debug_get_trace: the last traced render recorded " + std::to_string(sc->s.trace_levels) + " levels (max_depth + 1)");
+    DeviceGuard guard(sc->s.trace_device);
     HIP_OK(hipDeviceSynchronize());
     HIP_OK(hipMemcpy(out, sc->s.d_trace, (size_t)n_levels * 16u * sizeof(double), hipMemcpyDeviceToHost));
     return 0;

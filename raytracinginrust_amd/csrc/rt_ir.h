@@ -43,6 +43,7 @@ enum Feat : uint32_t {
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
+    F_COOP = 1u << 9,       // not a scene feature: lock-step loop whose bare BVH objects are walked by all lanes of the wave together (RT_COOP_BVH)
     F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
 

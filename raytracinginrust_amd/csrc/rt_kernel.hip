@@ -1302,6 +1302,206 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
     if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], n_active); }      // (both wave-uniform: kept in scalar registers)
 }
 
+// ------------------------------------------------------------------ lane-cooperative BVH walk (F_COOP instantiations, RT_COOP_BVH)
+// A BVH object that stands beside others is entered by a minority of a wave's lanes (*measured*, round 3: 12 of 59 for the final scene's
+// sphere cluster, 27 for its ground boxes, 26 of 63 for the teapot), which then walk a hundred nodes while the others wait.  Here the
+// waiting lanes WALK FOR THEM.  The threaded preorder walk of a ray is a contiguous range [node, end) of the recursion's node sequence;
+// a lane that enters an inner node N may hand the range [N.right, end) to an idle lane (which takes a copy of the ray) and keep
+// [N.left, N.right) — the helper walks what the recursion would reach later, at the same time, and may split again.  Ray state never
+// leaves registers: a hand-over is two dozen cross-lane register reads (ds_bpermute), nothing goes through memory.
+//
+// Exactness.  BVH::hit (bvh.rs:77-91) offers every node [t_min, closest-so-far]; a later range cannot know the hits of an earlier one, so
+// it walks with a BOUND instead: a value that is provably >= the closest hit the recursion holds when it reaches any node of the range.
+//   (1) Containment: a child's box lies inside its parent's (aabb.rs:40-51) and subtraction, multiplication by 1/d, min and max are
+//       monotonic, so a node's slab interval [t_in, t_far] lies inside every ancestor's — in floating point.  Hence the recursion tests
+//       the primitives of leaf X exactly when X's OWN box passes with the closest hit c it holds then: c > t_in(X) (and t_far(X) >
+//       t_in(X), which does not depend on c), and it tests them with t_max = c.
+//   (2) A leaf's primitives tested with any t_max >= c give the recursion's answer once compared with c: the range's winner t* (minimum,
+//       later primitive on ties) is the winner under c iff t* <= c, otherwise nothing is hit (rect.rs:49-60, sphere.rs:56-74 — whose
+//       second root is never below the first —, tri.rs:24-41).
+//   (3) So leaf X contributes the function  c -> (c > t_in(X) && t*(X) <= c) ? t*(X) : c,  and after X the recursion's closest hit is at
+//       most max(t*(X), t_in(X)).  That value — from leaves EARLIER in the recursion's order only — is the bound a lane walks with: a box
+//       or primitive it rejects, the recursion rejects too (its closest hit is smaller still).  What a lane keeps of its range is the
+//       last accepted leaf (t_in, t*, primitive): an earlier accepted leaf k1 of the same lane can be forgotten when the next one, k2,
+//       has t_in(k2) < t*(k1) and t*(k2) <= t*(k1) (then k2 is accepted whenever k1 was, with the same outcome) — always true unless
+//       t*(k1) <= t_in(k1), a primitive hit that rounding put in front of its own box, and k2 falls into that one-ulp gap: the lane
+//       then raises `dirty`, and the ray is walked again by the plain loop (never observed to matter; counted in stats[13]).
+//   (4) At the end the ray's owner folds the kept leaves of its ranges in the recursion's order — its own range's first, exact because
+//       that range walked with the true closest hit, then along the `next` links — with exactly the comparison of (3).
+// Rays that are not tame (NaNs possible) and near-first order do not take this path.
+#ifndef RT_COOP_MIN_FREE
+#define RT_COOP_MIN_FREE 2u      // a hand-over round (about two box steps' worth of cross-lane traffic) needs at least this many idle lanes
+#endif
+DEV uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
+DEV uint32_t fperm(uint32_t dst_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst_lane << 2), (int)v); }
+DEV double bperm(uint32_t src_lane, double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    const uint32_t lo = bperm(src_lane, (uint32_t)u), hi = bperm(src_lane, (uint32_t)(u >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+DEV float bperm(uint32_t src_lane, float x) { return __uint_as_float(bperm(src_lane, __float_as_uint(x))); }
+template <typename T> DEV V3<T> bperm3(uint32_t s, V3<T> v) { return mk<T>(bperm(s, v.x), bperm(s, v.y), bperm(s, v.z)); }
+struct CoopStats { unsigned long long steps, step_lanes, splits, fallbacks; };
+
+// All 64 lanes call this together (uniform control flow).  `enter`: this lane's ray r walks the tree at `root` and is offered
+// [t_min, t_max]; the others lend their lanes.  Returns (for entering lanes) whether something was hit, t_out / prim_out as bvh_hit_ww;
+// `redo` comes back set for an entering lane whose result must be recomputed by the plain walk (see (3) above).
+template <typename T, uint32_t FEATS>
+DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, uint32_t root, const RayT<T>& r, T t_min, T t_max, T& t_out, uint32_t& prim_out,
+                      bool& redo, CoopStats& cs) {
+    const uint32_t NONE = 0xFFFFFFFFu, NO_LANE = 0xFFu;
+    RayT<T> w = r;                                        // the ray this lane walks for: its own, or (after a hand-over) a borrowed copy
+    V3<T> inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
+    T bound = t_max;                                      // >= the recursion's closest hit at every node of this lane's range
+    uint32_t node = enter ? root : NONE, end = NONE;      // the range still to walk: [node, end) in the recursion's order
+    uint32_t cand = NONE;                                 // right child of the inner node entered most recently without a hand-over since
+    T k_tin = T(0), k_t = T(0); uint32_t k_prim = NONE;   // the leaf this lane keeps: its box's t_in, its winner (t*, primitive)
+    uint32_t next = NO_LANE, prev = NO_LANE;              // the lanes that walk the range following / preceding this one (same ray)
+    bool lent = false, dirty = false, have_leaf = false;
+    bool head = enter;                                    // walks the FIRST range of its own ray: bound is the true closest hit
+    for (;;) {
+        for (;;) {
+            const bool want_box = node != NONE && !have_leaf;
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
+            if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
+#pragma unroll
+            for (int k = 0; k < RT_BOX_STEPS; k++) {
+                const bool go = node != NONE && !have_leaf;
+                cs.steps++; cs.step_lanes += (unsigned long long)__popcll(__ballot(go));
+                if (go) {
+                    const DBvhNode<T> nd = fetch_node(P, node);
+                    const bool inside = box_inside_tame(nd, w.o, inv, t_min, bound);
+                    const bool leaf = (nd.a & BVH_LEAF) != 0u;
+                    if (inside && leaf) have_leaf = true;                 // the leaf stays the lane's node until the leaf step has tested it
+                    else {
+                        if (inside && cand == NONE) cand = nd.b;          // [nd.b, end) can go to a helper while this lane walks [nd.c, nd.b)
+                        node = inside ? nd.c : nd.skip;
+                        if (node == cand) cand = NONE;                    // arrived there itself
+                        if (node == end) node = NONE;
+                    }
+                }
+            }
+            // ---- hand-over round: lanes holding a range to give away meet lanes with nothing to do
+            const bool is_giver = cand != NONE && node != NONE;
+            // (a) a helper whose range is finished and left nothing — typically the right sibling's box failed at once — goes back to work
+            //     for its chain predecessor: same ray, and the new range [cand, end of the giver) ends where the helper's old one began, so
+            //     the chain's order holds.  Four values cross lanes, the ray stays where it is.
+            const bool spent = lent && node == NONE && k_prim == NONE && !have_leaf;
+            bool gave = false;
+            if (__ballot(spent) != 0ull && __ballot(is_giver && next != NO_LANE) != 0ull) {
+                const uint32_t nx = next != NO_LANE ? next : lane;
+                const bool regive = is_giver && next != NO_LANE && bperm(nx, spent ? 1u : 0u) != 0u;
+                const uint32_t pv = spent ? prev : lane;
+                const uint32_t p_cand = bperm(pv, regive ? cand : NONE), p_end = bperm(pv, end);
+                const T p_bound = bperm(pv, bound);
+                if (spent && p_cand != NONE) { node = p_cand; end = p_end; bound = p_bound; if (node == end) node = NONE; }      // (prev(next(G)) == G always)
+                if (regive) { end = cand; gave = true; cs.splits++; }
+            }
+            // (b) the others meet lanes that have not walked for anybody yet
+            const bool idle = node == NONE && k_prim == NONE && next == NO_LANE && !lent && !head;
+            const bool idle_head = head && node == NONE && k_prim == NONE && next == NO_LANE;      // an owner that is finished without a hit
+            const bool is_free = idle || idle_head;
+            const bool want = is_giver && !gave;
+            const unsigned long long Gm = __ballot(want), Fm = __ballot(is_free);
+            const uint32_t nG = (uint32_t)__popcll(Gm), nF = (uint32_t)__popcll(Fm);
+            if (nG != 0u && nF >= RT_COOP_MIN_FREE) {
+                const uint32_t kk = nG < nF ? nG : nF;
+                const uint32_t rg = lane_rank(Gm), rf = lane_rank(Fm);
+                // two stable partitions of the lane ids: givers first / free lanes first (a permutation each: no two lanes send to one)
+                const uint32_t g_at = fperm(want ? rg : nG + (lane - rg), lane);           // lane j < nG holds the j-th giver's id
+                const uint32_t f_at = fperm(is_free ? rf : nF + (lane - rf), lane);        // lane j < nF holds the j-th free lane's id
+                const uint32_t my_helper = bperm(rg, f_at), my_src = bperm(rf, g_at);
+                const bool give = want && rg < kk, take = is_free && rf < kk;
+                // the giver's old successor learns its new predecessor (prev(next(G)) == G stays true)
+                const uint32_t pv = prev != NO_LANE ? prev : lane;
+                const uint32_t p_helper = bperm(pv, give ? my_helper : NO_LANE);
+                if (prev != NO_LANE && p_helper != NO_LANE) prev = p_helper;
+                const uint32_t s = take ? my_src : lane;                                   // (everyone else reads its own registers back)
+                w.o = bperm3(s, w.o); w.d = bperm3(s, w.d); inv = bperm3(s, inv);
+                if (FEATS & F_SPHERES) w.tm = bperm(s, w.tm);                               // (only moving spheres read the ray's time)
+                bound = bperm(s, bound);
+                const uint32_t src_cand = bperm(s, cand), src_end = bperm(s, end), src_next = bperm(s, next);
+                if (take) { node = src_cand; end = src_end; next = src_next; prev = my_src; lent = true; head = false; if (node == end) node = NONE; }
+                if (give) { end = cand; next = my_helper; }
+                cs.splits += kk;
+            }
+            cand = NONE;            // (a range offered in this round and not taken is not offered again: the lane has walked on since)
+        }
+        if (have_leaf) {
+            const DBvhNode<T> lf = fetch_node(P, node);
+            T t; uint32_t prim;
+            if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, w, t_min, bound, t, prim)) {
+                // t_in of the leaf's own box, as AABB::hit computes it (box_inside_tame)
+                const T ax = (lf.mn[0] - w.o.x) * inv.x, bx = (lf.mx[0] - w.o.x) * inv.x;
+                const T ay = (lf.mn[1] - w.o.y) * inv.y, by = (lf.mx[1] - w.o.y) * inv.y;
+                const T az = (lf.mn[2] - w.o.z) * inv.z, bz = (lf.mx[2] - w.o.z) * inv.z;
+                const T tin = max_nn(max_nn(max_nn(min_nn(ax, bx), t_min), min_nn(ay, by)), min_nn(az, bz));
+                if (head) bound = t;                                   // the first range IS the recursion: closest = t (hit.rs:62-69)
+                else {
+                    if (k_prim != NONE && !(tin < k_t && t <= k_t)) dirty = true;
+                    bound = t > tin ? t : tin;
+                }
+                k_tin = tin; k_t = t; k_prim = prim;
+            }
+            node = lf.skip;
+            if (node == end) node = NONE;
+            have_leaf = false;
+        }
+        if (__ballot(node != NONE) == 0ull) break;
+    }
+    // ---- the owner folds the kept leaves of its ray's ranges, in the recursion's order
+    T c = t_max; uint32_t rp = NONE; bool any = false, bad = false;
+    const bool own = enter && !lent;                       // (an owner that lent its lane had finished without a hit and without helpers)
+    if (own && k_prim != NONE) { c = k_t; rp = k_prim; any = true; }
+    uint32_t cur = own ? next : NO_LANE;
+    while (__ballot(cur != NO_LANE) != 0ull) {
+        const bool on = cur != NO_LANE;
+        const uint32_t s = on ? cur : lane;
+        const T h_tin = bperm(s, k_tin), h_t = bperm(s, k_t);
+        const uint32_t h_prim = bperm(s, k_prim), h_link = bperm(s, next | (dirty ? 0x100u : 0u));
+        if (on) {
+            if (h_prim != NONE && c > h_tin && h_t <= c) { c = h_t; rp = h_prim; any = true; }
+            if (h_link & 0x100u) bad = true;
+            cur = h_link & 0xFFu;
+        }
+    }
+    redo = bad;
+    if (bad) cs.fallbacks++;
+    t_out = c; prim_out = rp;
+    return any;
+}
+
+// world.hit (main.rs:48, hit.rs:59-71) with every lane of the wave present: `act` lanes search, the others lend their lanes to the
+// cooperative walk of bare BVH objects.  Same objects in the same order with the same [t_min, closest] as world_hit.
+template <typename T, uint32_t FEATS>
+DEV bool world_hit_coop(const KParams<T>& P, uint32_t lane, bool act, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack, CoopStats& cs) {
+    T closest = Lim<T>::inf();
+    bool any = false;
+    for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
+        const DObject ob = ld_obj(P.objects + oi);
+        if (!(ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0))) {
+            if (act) object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
+            continue;
+        }
+        RayT<T> r = ray;
+        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+        if (!act) { r.o = mk<T>(T(0), T(0), T(0)); r.d = mk<T>(T(1.0), T(1.0), T(1.0)); }       // (lanes without a path: a tame ray)
+        const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
+        const bool tame = P.bvh_tame != 0u && __ballot(act && !ray_is_tame(r.o, inv)) == 0ull;
+        T t = T(0); uint32_t prim = 0; bool hit = false;
+        if (tame) {
+            bool redo = false;
+            hit = bvh_hit_coop<T, FEATS>(P, lane, act, ob.geom_first, r, t_min, closest, t, prim, redo, cs);
+            if (__ballot(redo) != 0ull) {                    // (see bvh_hit_coop (3): the plain walk for those rays)
+                if (act && redo) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
+            }
+        } else if (act) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
+        if (act && hit) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+    }
+    t_hit = closest;
+    return any;
+}
+
 // ------------------------------------------------------------------ list scenes: lock-step bounce loop
 // Every iteration: dead lanes regenerate, then all 64 lanes run one level of ray_color together (closest hit over the
 // wave-uniform object list, hit record, material).  Used when the scene has no BVH: every lane's closest-hit search costs
@@ -1321,6 +1521,8 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0;
+    constexpr bool COOP = (FEATS & F_COOP) != 0u;       // bare BVH objects are walked by the whole wave together (bvh_hit_coop)
+    CoopStats cs; cs.steps = cs.step_lanes = cs.splits = cs.fallbacks = 0ull;
     DIAG_DECL
 
     for (;;) {
@@ -1347,14 +1549,16 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_ADD(1);
 
         // ---- one level of ray_color (main.rs:41-120) for every live lane
+        T t_hit = T(0); HitId id; id.obj = 0; id.prim = 0;
+        bool any_hit = false;
+        if (COOP) any_hit = world_hit_coop<T, FEATS>(P, lane, alive && depth_left != 0u, ray, TMin<T>::v(), rng, t_hit, id, stack, cs);   // main.rs:48, every lane present
         if (alive) {
             bool done = false;
             V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
             if (depth_left == 0) {
                 done = true;                            // main.rs:42-45
             } else {
-                T t_hit; HitId id; id.obj = 0; id.prim = 0;
-                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
+                if (!COOP) any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
                 DIAG_ADD(2);
                 if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
@@ -1389,6 +1593,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
     write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
+    if (COOP && st && lane == 0) { atomicAdd(&st[9], cs.steps); atomicAdd(&st[10], cs.step_lanes); atomicAdd(&st[12], cs.splits); atomicAdd(&st[13], cs.fallbacks); }
 #ifdef RT_DIAG
     if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
@@ -1674,13 +1879,16 @@ template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<do
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
+    const bool co = (flags & 256u) && (scene_feats & F_BVH) && !nf && !ps;      // RT_COOP_BVH (reference-order lock-step family)
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
+        if (co) return f(std::integral_constant<uint32_t, FEATS_MESH | F_COOP>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
-        if ((flags & 1024u) && !nf && !ps) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
+        if (co) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_COOP>());
+        if ((flags & 1024u) && !nf && !ps && !co) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
     }

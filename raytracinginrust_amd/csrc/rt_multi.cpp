@@ -186,7 +186,8 @@ bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint3
             if (!virtual_ranks && !ensure_buffer(c.d_tiles, c.tiles_bytes, tiles_bytes, perr[r])) return;
             if (r == 0) {
                 if ((collective || virtual_ranks) && !ensure_buffer(c.d_gather, c.gather_bytes, tiles_bytes * N, perr[r])) return;
-                if (!ensure_buffer(c.d_frame, c.frame_bytes, (size_t)n_px * 3 * sizeof(double), perr[r])) return;
+                const int fb = (int)(s.multi_frames & 1ull);      // consecutive frames alternate between two frame buffers
+                if (!ensure_buffer(c.d_frame[fb], c.frame_bytes[fb], (size_t)n_px * 3 * sizeof(double), perr[r])) return;
             }
         };
         if (n_distinct == 1) prep(0);
@@ -235,6 +236,8 @@ bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint3
         }
     }
     // ---- every device: its share of the tiles, asynchronously on its own stream (one thread: a launch is a few microseconds)
+    s.frame_group++; s.group_open = true;          // the N launches are ONE frame: rt_last_stats sums their counters
+    struct CloseGroup { Scene& s; ~CloseGroup() { s.group_open = false; } } close_group{s};
     for (uint32_t r = 0; r < N; r++) {
         if ((e = hipSetDevice(devs[r])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
         if ((long)r == fail_rank) { err = "rank " + std::to_string(r) + ": injected failure (RT_MULTI_FAIL_RANK)"; return false; }
@@ -264,7 +267,7 @@ bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint3
     const unsigned long long n_out = n_px * 3ull;
     const unsigned block = 256; const unsigned long long grid = (n_out + block - 1) / block;
     hipLaunchKernelGGL(unpermute_tiles, dim3((unsigned)grid), dim3(block), 0, rs,
-                       (const double*)((collective || virtual_ranks) ? root.d_gather : rank_tiles[0]), (double*)root.d_frame, n_px, tile_px, N, (unsigned long long)n_local);
+                       (const double*)((collective || virtual_ranks) ? root.d_gather : rank_tiles[0]), (double*)root.d_frame[s.multi_frames & 1ull], n_px, tile_px, N, (unsigned long long)n_local);
     if ((e = hipGetLastError()) != hipSuccess) { err = hip_msg("un-permute launch", e); return false; }
     if ((e = hipEventRecord((hipEvent_t)s.multi_ev[2], rs)) != hipSuccess) { err = hip_msg("hipEventRecord", e); return false; }
     return true;
@@ -329,7 +332,10 @@ int rt_render_multi_device(rt_scene* sc, const rt_camera* cam, const double bg[3
         s.multi_devs = devs_before; drain(s); s.multi_devs = devs_now;
     }
     s.multi_pending = ok;
-    if (ok && d_frame_out) *d_frame_out = s.ctx_for(s.multi_devs[0]).d_frame;
+    if (ok) {
+        if (d_frame_out) *d_frame_out = s.ctx_for(s.multi_devs[0]).d_frame[s.multi_frames & 1ull];
+        s.multi_frame_doubles = (size_t)W * H * 3; s.multi_frames++;
+    }
     (void)hipSetDevice(cur);                        // a PyTorch host keeps its current device
     return ok ? 0 : set_error(err);
 }
@@ -345,8 +351,13 @@ int rt_multi_copy_frame(rt_scene* sc, double* rgb_sum_out, size_t n_doubles) {
     if (settle(s)) return -1;
     if (s.multi_devs.empty()) return set_error("no rt_render_multi frame has been rendered for this scene");
     Scene::DeviceCtx& root = s.ctx_for(s.multi_devs[0]);
-    if (!root.d_frame || n_doubles * sizeof(double) > root.frame_bytes) return set_error("rt_multi_copy_frame: more doubles asked for than the last frame holds");
-    const hipError_t e = hipMemcpy(rgb_sum_out, root.d_frame, n_doubles * sizeof(double), hipMemcpyDeviceToHost);
+    if (s.multi_frames == 0) return set_error("no rt_render_multi frame has been rendered for this scene");
+    const void* frame = root.d_frame[(s.multi_frames - 1ull) & 1ull];          // the most recent frame's buffer
+    if (!frame || n_doubles > s.multi_frame_doubles) return set_error("rt_multi_copy_frame: more doubles asked for than the last frame holds (W*H*3)");
+    int cur = 0; (void)hipGetDevice(&cur);
+    (void)hipSetDevice(s.multi_devs[0]);
+    const hipError_t e = hipMemcpy(rgb_sum_out, frame, n_doubles * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipSetDevice(cur);
     return e == hipSuccess ? 0 : set_error(hip_msg("hipMemcpy(frame)", e));
 }
 

@@ -68,6 +68,7 @@ struct Scene {
         void* d_queue = nullptr; void* d_stats = nullptr;
         void* ev_start = nullptr; void* ev_stop = nullptr;
         void* stream = nullptr; bool recorded = false, timed = true; unsigned long long seq = 0;
+        unsigned long long group = 0; bool harvested = true;   // the frame this launch is a share of; its counters have joined Scene::acc_stats
     };
     // Everything that lives on ONE HIP device: the replicated scene tables (the scene is < 2 MB: every device that renders
     // a share of the frame holds its own copy), launch scratch, and rt_render_multi's per-device buffers.
@@ -80,7 +81,7 @@ struct Scene {
         void* stream = nullptr;            // rt_render_multi: this device's stream, tile buffer, and (root only) gather / frame buffers
         void* d_tiles = nullptr; size_t tiles_bytes = 0;
         void* d_gather = nullptr; size_t gather_bytes = 0;
-        void* d_frame = nullptr; size_t frame_bytes = 0;
+        void* d_frame[2] = {nullptr, nullptr}; size_t frame_bytes[2] = {0, 0};      // root only: consecutive frames alternate, so that frame i can still be read while frame i + 1 is un-permuted
     };
     std::vector<DeviceCtx*> ctxs;          // created on first use of a device
     int last_device = -1;                  // device of the most recent launch (what rt_last_* report)
@@ -96,9 +97,14 @@ struct Scene {
     void* multi_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int multi_ev_device = -1;
     std::vector<void*> virtual_tiles; size_t virtual_tiles_bytes = 0; int virtual_tiles_device = -1;
     double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
+    // One frame may be several launches (rt_render_multi: one per device or virtual rank).  Every launch carries its frame's number;
+    // the counters of a frame's launches are summed in acc_stats (rt_last_stats reports the whole frame, not one rank's share).
+    unsigned long long frame_group = 0; bool group_open = false;      // group_open: rt_render_multi is enqueueing the launches of ONE frame
+    unsigned long long acc_group = 0; unsigned long long acc_stats[16] = {0};
+    unsigned long long multi_frames = 0; size_t multi_frame_doubles = 0;      // rt_render_multi* frames enqueued so far; W*H*3 of the most recent one
 
     // debugging aid (rt_debug_trace_path; -DRT_TRACE_PATH builds of the kernels): the path whose hits are recorded, and the device buffer
-    long long trace_px = -1, trace_s = -1; void* d_trace = nullptr; int trace_device = -1;
+    long long trace_px = -1, trace_s = -1; void* d_trace = nullptr; int trace_device = -1; uint32_t trace_levels = 0;     // trace_levels: 16-double records d_trace holds
 
     void invalidate() { flat_valid = false; }
     DeviceCtx& ctx_for(int device) {

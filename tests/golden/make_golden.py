@@ -47,6 +47,34 @@ def make_grid_goldens(be, earth):
         print(key, sums.shape, float(sums.sum()) / (w.W * w.H * spp), int(bad.sum()))
 
 
+# BASELINE configs 2-5 at their FULL sample counts on two bands of rows of their own frames: a band in the middle of the image and the
+# top row (output row 0).  Per-pixel sums of the oracle — what links samples 16..1023 / 4..4095 / 2..2047 / 1..8191 of every pixel, the
+# 256-sample tail chunks and the pixel x spp > 2^32 bookkeeping of the product's full-frame launch to the oracle per pixel.
+BAND_ROWS = {"C2": 8, "C3": 2, "C4": 2, "C5": 1}
+
+
+def band_rows(key, H):
+    n = BAND_ROWS[key]
+    mid = H // 2 - n // 2
+    return [(mid, mid + n), (0, 1)]
+
+
+def make_band_goldens(be, earth, keys=None):
+    import time
+    from raytracinginrust_amd import workloads
+    for key in keys or BAND_ROWS:
+        w = workloads.WORKLOADS[key]
+        b, cam, bg = workloads.build(w, be, earth)
+        rows, sums = [], []
+        t0 = time.perf_counter()
+        for r0, r1 in band_rows(key, w.H):
+            out = orc.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth, seed=scenes.DEFAULT_SEED, rows=(r0, r1))
+            rows.append((r0, r1)); sums.append(out[r0:r1].copy())
+        np.savez_compressed(os.path.join(HERE, f"oracle_band_{key}.npz"), rows=np.array(rows), band0=sums[0], band1=sums[1], W=w.W, H=w.H, spp=w.spp,
+                            depth=w.max_depth, seed=scenes.DEFAULT_SEED)
+        print(key, rows, [float(np.nanmean(x)) / w.spp for x in sums], [int((~np.isfinite(x)).sum()) for x in sums], f"{time.perf_counter() - t0:.1f} s")
+
+
 if __name__ == "__main__":
     earth = scenes.load_earthmap()          # the reference's own 1024x512 texture, decoded by the library's JPEG ingest
     be = orc.load()
@@ -57,3 +85,4 @@ if __name__ == "__main__":
                             seed=scenes.DEFAULT_SEED, bytes_per_sample=orc.algorithmic_bytes_per_sample(cnt, spp))
         print(name, out.shape, float(out.mean()) / spp, orc.algorithmic_bytes_per_sample(cnt, spp))
     make_grid_goldens(be, earth)
+    make_band_goldens(orc.load_nocount() if hasattr(orc, 'load_nocount') else be, earth)

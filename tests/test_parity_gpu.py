@@ -420,23 +420,59 @@ def test_two_frames_in_flight_give_the_same_frames(pbe):
         assert torch.allclose(f, ref, rtol=1e-12, atol=1e-12 * spp, equal_nan=True)
 
 
+_FULL = {}
+
+
+def _full_frame(key, pbe, earth):
+    """The BASELINE config's whole frame at its full sample count through ONE launch (what bench.py times), rendered once per test
+    session: (frame sums, kernel ms, non-finite samples, builder, camera, background)."""
+    if key not in _FULL:
+        from raytracinginrust_amd import workloads
+        w = workloads.WORKLOADS[key]
+        b, cam, bg = workloads.build(w, pbe, earth)
+        a = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
+        _FULL[key] = (a, R.last_kernel_ms(b), R.last_stats(b)["nonfinite_samples"], b, cam, bg)
+    return _FULL[key]
+
+
+@pytest.mark.parametrize("band", [0, 1], ids=["middle", "top"])
+@pytest.mark.parametrize("key", ["C2", "C3", "C4", "C5"])
+def test_full_spp_band_against_the_oracle(key, band, pbe, earth):
+    """BASELINE configs 2-5, the WHOLE frame at the FULL sample count through one launch (the bench's step), compared per pixel with the
+    oracle on two bands of rows — 8 / 2 / 2 / 1 rows in the middle of the image and the top row — whose oracle sums at full spp are
+    committed (tests/golden/oracle_band_*.npz, make_golden.py: make_band_goldens; the CPU suite checks that the oracle still produces
+    them).  This is what ties samples 16..1023 / 4..4095 / 2..2047 / 1..8191 of a pixel, the 256-sample tail chunks (32 per pixel at
+    C5) and the pixel x spp > 2^32 bookkeeping of the full-frame launch to the oracle: tolerance per pixel 1e-9 * (spp + |ref|), at
+    most MAX_DIVERGED pixels may hold a diverged sample (a path that took another branch after a last-ulp libm difference), non-finite
+    pixels equal."""
+    from raytracinginrust_amd import workloads
+    w = workloads.WORKLOADS[key]
+    g = np.load(golden_path(f"oracle_band_{key}.npz"))
+    assert (int(g["W"]), int(g["H"]), int(g["spp"]), int(g["depth"])) == (w.W, w.H, w.spp, w.max_depth)
+    a = _full_frame(key, pbe, earth)[0]
+    r0, r1 = (int(x) for x in g["rows"][band])
+    ref, got = g[f"band{band}"], a[r0:r1]
+    assert ref.shape == got.shape == (r1 - r0, w.W, 3)
+    fin = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), fin)
+    d = np.abs(np.where(fin, got, 0.0) - np.where(fin, ref, 0.0))
+    bad = (d > SAMPLE_RTOL * (w.spp + np.abs(np.where(fin, ref, 0.0)))).any(axis=-1)
+    assert bad.sum() <= MAX_DIVERGED, f"{int(bad.sum())} of {bad.size} pixels of rows {r0}..{r1 - 1} differ from the oracle at full spp (worst {d.max():.3e})"
+    print(f"{key} rows {r0}..{r1 - 1} at {w.spp} spp: {int(bad.sum())} pixels off, max |gpu - oracle| per pixel sum {d[~bad].max():.3e} "
+          f"(sums up to {np.abs(ref[fin]).max():.1f})")
+
+
 def test_full_size_cornell_properties(pbe, obe, orc_mod):
-    """BASELINE config 2: Cornell box 800x800, 1024 spp, depth 50.  The oracle cannot run this in seconds, so:
+    """BASELINE config 2: Cornell box 800x800, 1024 spp, depth 50 (the oracle link at full spp: test_full_spp_band_against_the_oracle).
     (1) two runs agree to summation-order rounding (the dynamic sample->lane assignment changes only the order);
-    (2) no non-finite sample; (3) the frame mean equals the oracle's mean over a coarser grid of the same
-    image within Monte-Carlo error; (4) a sharded render (8 ranks) reassembles to the same frame."""
+    (2) no non-finite sample; (3) a sharded render (8 ranks) reassembles to the same frame."""
     import torch
-    b, cam, bg = _cornell(pbe)
     W = H = 800
     spp, depth = 1024, 50
-    a = R.render(b, cam, bg, W, H, spp, depth)
-    ms = R.last_kernel_ms(b)
-    assert R.last_stats(b)["nonfinite_samples"] == 0
+    a, ms, n_bad, b, cam, bg = _full_frame("C2", pbe, None)
+    assert n_bad == 0
     c = R.render(b, cam, bg, W, H, spp, depth)
     assert np.all(np.abs(a - c) <= 1e-12 * (spp + np.abs(a)))
-    ob, ocam, obg = scenes.cornell_box(obe)
-    coarse = orc_mod.render(ob, ocam, obg, 100, 100, 64, depth, seed=7)
-    assert a.mean() / spp == pytest.approx(coarse.mean() / 64, rel=0.02)
     parts = []
     for rank in range(8):
         tr = D.TileRenderer(b, cam, bg, W, H, spp, depth, tile_px=64, rank=rank, world=8)
@@ -450,20 +486,15 @@ def test_full_size_cornell_properties(pbe, obe, orc_mod):
 def test_full_size_teapot_properties(pbe, obe, orc_mod):
     """BASELINE config 4 on one GPU: teapot room 1920x1080, 2048 spp, depth 50 (4.25 G samples).  (1) the persistent-traversal
     loop (default here) and the lock-step loop give the same frame to summation-order rounding; (2) no non-finite sample;
-    (3) frame mean vs the oracle on a coarser grid of the same image; (4) 8 interleaved shards reassemble to the frame."""
+    (3) 8 interleaved shards reassemble to the frame.  (The oracle link at full spp: test_full_spp_band_against_the_oracle.)"""
     import torch
     from raytracinginrust_amd import workloads
     w = workloads.WORKLOADS["C4"]
-    b, cam, bg = workloads.build(w, pbe)
-    a = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
-    ms = R.last_kernel_ms(b)
-    assert R.last_traversal_stats(b)["traversal_steps"] > 0 and R.last_stats(b)["nonfinite_samples"] == 0
+    a, ms, n_bad, b, cam, bg = _full_frame("C4", pbe, None)
+    assert n_bad == 0
     c = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=R.RT_LOCKSTEP_BVH)
     assert np.all(np.abs(a - c) <= 1e-12 * (w.spp + np.abs(a)))
     del c
-    ob, ocam, obg = workloads.build(w, obe)
-    coarse = orc_mod.render(ob, ocam, obg, 160, 90, 32, w.max_depth, seed=11)
-    assert a.mean() / w.spp == pytest.approx(coarse.mean() / 32, rel=0.03)
     parts = []
     for rank in range(8):
         tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, tile_px=D.DEFAULT_TILE_PX, rank=rank, world=8)
@@ -476,24 +507,17 @@ def test_full_size_teapot_properties(pbe, obe, orc_mod):
 
 def test_full_size_final_scene_properties(pbe, obe, orc_mod, earth):
     """BASELINE config 3: final scene 800x800, 4096 spp, depth 50 (2.62 G samples).  Two runs agree to summation-order rounding
-    with the same pixels poisoned by non-finite samples (the reference's 0/0 cases), and the mean of the finite pixels matches
-    the oracle's on a coarser grid."""
+    with the same pixels poisoned by non-finite samples (the reference's 0/0 cases).  (The oracle link at full spp:
+    test_full_spp_band_against_the_oracle.)"""
     from raytracinginrust_amd import workloads
     w = workloads.WORKLOADS["C3"]
-    b, cam, bg = workloads.build(w, pbe, earth)
-    a = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
-    ms = R.last_kernel_ms(b)
-    n_bad = R.last_stats(b)["nonfinite_samples"]
+    a, ms, n_bad, b, cam, bg = _full_frame("C3", pbe, earth)
     c = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
     assert R.last_stats(b)["nonfinite_samples"] == n_bad
     assert np.array_equal(np.isfinite(a), np.isfinite(c))
     fin = np.isfinite(a)
     assert (~fin).any(axis=-1).sum() <= n_bad                    # every poisoned pixel holds at least one counted sample
     assert np.all(np.abs(a[fin] - c[fin]) <= 1e-12 * (w.spp + np.abs(a[fin])))
-    ob, ocam, obg = workloads.build(w, obe, earth)
-    coarse = orc_mod.render(ob, ocam, obg, 100, 100, 32, w.max_depth, seed=13)
-    cf = np.isfinite(coarse)
-    assert a[fin].mean() / w.spp == pytest.approx(coarse[cf].mean() / 32, rel=0.05)
     print(f"C3 {w.W}x{w.H}x{w.spp} f64: {ms:.0f} ms, {w.samples / ms / 1e3:.0f} Msamples/s, {n_bad} non-finite samples")
 
 
@@ -571,16 +595,14 @@ def test_c5_full_sample_count(pbe, obe, orc_mod):
     """BASELINE config 5 at its real sample count: Cornell box 3840x2160 (src/main.rs:579-583 scaled), 8192 spp, depth 50 =
     67.9 G samples (pixels x spp > 2^32; 32 work chunks per pixel).  The whole frame on ONE GPU, then rank 0's share of the
     8-GPU decomposition at the same spp: (1) no non-finite sample; (2) the share's tiles equal the whole frame's pixels to
-    summation-order rounding (sharded == unsharded at full spp); (3) the share is reproducible; (4) the frame mean matches the
-    oracle's on a coarse grid of the same image within Monte-Carlo error."""
+    summation-order rounding (sharded == unsharded at full spp); (3) the share is reproducible.  (The oracle link at full spp:
+    test_full_spp_band_against_the_oracle.)"""
     import torch
     from raytracinginrust_amd import workloads
     w = workloads.WORKLOADS["C5"]
     assert w.W * w.H * w.spp > 2 ** 32
-    b, cam, bg = workloads.build(w, pbe)
-    full = R.render(b, cam, bg, w.W, w.H, w.spp, w.max_depth)
-    ms = R.last_kernel_ms(b)
-    assert R.last_stats(b)["nonfinite_samples"] == 0 and np.isfinite(full).all()
+    full, ms, n_bad, b, cam, bg = _full_frame("C5", pbe, None)
+    assert n_bad == 0 and np.isfinite(full).all()
     tile = D.DEFAULT_TILE_PX
     tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, tile_px=tile, rank=0, world=8)
     share = tr.render_local().clone(); torch.cuda.synchronize()
@@ -597,9 +619,6 @@ def test_c5_full_sample_count(pbe, obe, orc_mod):
             assert not share[q].any()                            # padding tile
             continue
         assert np.all(np.abs(share[q, : hi - lo] - flat[lo:hi]) <= 1e-12 * (w.spp + np.abs(flat[lo:hi])))
-    ob, ocam, obg = workloads.build(w, obe)
-    coarse = orc_mod.render(ob, ocam, obg, 192, 108, 64, w.max_depth, seed=17)
-    assert full.mean() / w.spp == pytest.approx(coarse.mean() / 64, rel=0.02)
     print(f"C5 {w.W}x{w.H}x{w.spp} f64 on one GPU: {ms / 1e3:.2f} s, {w.samples / ms / 1e3:.0f} Msamples/s; rank 0's 1/8 share {ms_share:.0f} ms "
           f"(x8 = {8 * ms_share / 1e3:.2f} s)")
 

@@ -1,0 +1,41 @@
+"""Developer probe for the lane-cooperative BVH walk (RT_COOP_BVH): on each scene the samples of the cooperative loop against the plain
+lock-step loop (differing 64-bit words), the kernel times of both (and of the default loop), and the walk's counters (box steps, lanes
+per step, hand-overs, redone rays).   usage: python tools/coop_probe.py [scene ...]   (RT_AMD_LIB selects the build)"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import numpy as np
+import torch  # noqa: F401
+from raytracinginrust_amd import _lib, render as R, scenes
+be = _lib.load()
+earth = scenes.load_earthmap()
+names = sys.argv[1:] or ['final', 'teapot', 'random', 'mesh0', 'mesh3']
+def build(name):
+    if name == 'final': return scenes.final_scene(be, *earth)
+    if name == 'teapot': return scenes.cornell_test(be, scenes.asset_path('teapot.obj'))
+    if name == 'random': return scenes.random_scene(be, aspect_ratio=1.0)
+    from test_parity_gpu import _mesh_room
+    return _mesh_room(be, int(name[4:]))
+for name in names:
+    b, cam, bg = build(name)
+    W, H, spp, depth = 96, 64, 8, 30
+    _, ref = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH, want_samples=True)
+    _, got = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_COOP_BVH, want_samples=True)
+    ts = R.last_traversal_stats(b)
+    bad = int((ref.view(np.uint64) != got.view(np.uint64)).sum())
+    print(f'{name}: small frame, differing words {bad} of {ref.size}; box steps {ts["traversal_steps"]}, lanes/step {ts["traversal_lanes"] / max(1, ts["traversal_steps"]):.1f}, '
+          f'hand-overs {ts["leaf_steps"]}, redone rays {ts["leaf_lanes"]}', flush=True)
+    W = H = 400; spp = 64
+    res = {}
+    for tag, fl in (('default', 0), ('lockstep', R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH), ('coop', R.RT_LOCKSTEP_BVH | R.RT_COOP_BVH)):
+        ms = []
+        for _ in range(3):
+            out = R.render(b, cam, bg, W, H, spp, 50, flags=fl)
+            ms.append(R.last_kernel_ms(b))
+        res[tag] = (min(ms), out)
+        extra = ''
+        if tag == 'coop':
+            ts = R.last_traversal_stats(b)
+            extra = f'  steps {ts["traversal_steps"]}, lanes/step {ts["traversal_lanes"] / max(1, ts["traversal_steps"]):.1f}, hand-overs {ts["leaf_steps"]}, redone {ts["leaf_lanes"]}'
+        print(f'    {tag:9s} {min(ms):8.3f} ms  {W * H * spp / min(ms) / 1e3:8.1f} Msamples/s{extra}', flush=True)
+    d = np.abs(res['coop'][1] - res['lockstep'][1]); fin = np.isfinite(d)
+    print(f'    frame sums coop vs lockstep: max |diff| {d[fin].max():.3e}, non-finite pattern equal: {bool(np.array_equal(np.isfinite(res["coop"][1]), np.isfinite(res["lockstep"][1])))}')
