@@ -136,13 +136,16 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
     model = bps * local_samples / (k_ms * 1e-3) / 1e9
     roof = {"bound": "f64_valu", "achieved": achieved, "peak": peak, "unit": "Tops/s (f64 VALU issue-equivalents: lane-operations weighted by issue cost)",
             "frac": achieved / peak,
+            "peak_measured_issue": workloads.F64_VALU_MEASURED_ISSUE_OPS / 1e12, "frac_of_measured_issue": achieved / (workloads.F64_VALU_MEASURED_ISSUE_OPS / 1e12),
             "traffic": None, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, KB counters x 1024; raw values)",
             "traffic_source": None, "hbm_measured_GBps": None, "hbm_measured_frac": None,
             "ops_per_sample": ops, "flops_per_sample_unweighted": workloads.flops(per_kind),
             "achieved_unweighted_TFLOPs": workloads.flops(per_kind) * local_samples / (k_ms * 1e-3) / 1e12,
             "ops_per_sample_source": "raytracinginrust_amd/workloads.py F64_OPS_PER_SAMPLE x VALU_OP_WEIGHTS (the reference's f64 operations by kind, counted by "
                                      "the op-counting build of the CPU oracle on this workload's own grid; tests/sweeps/measure_ops_per_sample.py)",
-            "peak_source": "256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2.4 GHz = 39.3e12 lane-operations/s (78.6 TFLOP/s spec counts an FMA as 2; the path has none)",
+            "peak_source": "256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2.4 GHz = 39.3e12 lane-operations/s (78.6 TFLOP/s spec counts an FMA as 2; the path has none); "
+                           "peak_measured_issue = what a stream of independent f64 adds / multiplies sustains, 64 lanes / 4.92 cycles x 2.26 GHz x 1024 SIMDs "
+                           "(profiles/r04_ubench.csv: the weights are cycles relative to that same 4.92)",
             "kernel": kernel_name, "kernel_ms": k_ms, "samples_per_launch": local_samples,
             "framebuffer_atomics_per_launch": 3 * n_flush,       # what the kernel itself counted in THIS run: f64 atomic adds, 8 B each
             "framebuffer_atomic_bytes_per_launch": 24 * n_flush,

@@ -33,7 +33,7 @@ static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_er
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> static void free_device_scene(DeviceScene<T>& d) {
     free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
-    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
+    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.frontier); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
     d.valid = false;
 }
 
@@ -411,6 +411,7 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
     if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
     if (upload_raw(f.lights, d.lights)) return -1;
+    if (upload_raw(f.bvh_frontier, d.frontier)) return -1;
     std::vector<DPerlin<T>> pl(s.perlins.size());
     for (size_t i = 0; i < pl.size(); i++) {
         for (int k = 0; k < 768; k++) pl[i].rd_vec[k] = (T)s.perlins[i].rd_vec[k];
@@ -553,6 +554,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.n_bvh = (uint32_t)f.bvh.size();
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
+    P.bvh_frontier = (const uint32_t*)d.frontier;
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
         const double big = sizeof(T) == 8 ? 1e300 : 1e30;

@@ -1305,32 +1305,36 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
 // ------------------------------------------------------------------ lane-cooperative BVH walk (F_COOP instantiations, RT_COOP_BVH)
 // A BVH object that stands beside others is entered by a minority of a wave's lanes (*measured*, round 3: 12 of 59 for the final scene's
 // sphere cluster, 27 for its ground boxes, 26 of 63 for the teapot), which then walk a hundred nodes while the others wait.  Here the
-// waiting lanes WALK FOR THEM.  The threaded preorder walk of a ray is a contiguous range [node, end) of the recursion's node sequence;
-// a lane that enters an inner node N may hand the range [N.right, end) to an idle lane (which takes a copy of the ray) and keep
-// [N.left, N.right) — the helper walks what the recursion would reach later, at the same time, and may split again.  Ray state never
-// leaves registers: a hand-over is two dozen cross-lane register reads (ds_bpermute), nothing goes through memory.
+// waiting lanes WALK FOR THEM.  The threaded preorder walk of a ray is a sequence of nodes; the flattener cuts every tree at depth
+// RT_FRONTIER_DEPTH into S <= 16 subtrees F[0] .. F[S-1] in the recursion's order (KParams::bvh_frontier), subtree j being the
+// contiguous piece [F[j], F[j+1]) of that sequence.  A ray that enters the tree gets a group of k lanes — its own and k - 1 of the
+// lanes whose rays do not enter — and lane i of the group walks the subtrees [i S / k, (i + 1) S / k): one contiguous range [node, end)
+// each, all at the same time.  Ray state never leaves registers: a helper takes a copy of the ray with sixteen cross-lane register
+// reads (ds_bpermute) once per walk, nothing goes through memory, and the step loop is the plain walk's plus one compare.
 //
 // Exactness.  BVH::hit (bvh.rs:77-91) offers every node [t_min, closest-so-far]; a later range cannot know the hits of an earlier one, so
 // it walks with a BOUND instead: a value that is provably >= the closest hit the recursion holds when it reaches any node of the range.
 //   (1) Containment: a child's box lies inside its parent's (aabb.rs:40-51) and subtraction, multiplication by 1/d, min and max are
 //       monotonic, so a node's slab interval [t_in, t_far] lies inside every ancestor's — in floating point.  Hence the recursion tests
 //       the primitives of leaf X exactly when X's OWN box passes with the closest hit c it holds then: c > t_in(X) (and t_far(X) >
-//       t_in(X), which does not depend on c), and it tests them with t_max = c.
+//       t_in(X), which does not depend on c), and it tests them with t_max = c.  (So a range may start below the root without testing
+//       the boxes above it: they only ever cull.)
 //   (2) A leaf's primitives tested with any t_max >= c give the recursion's answer once compared with c: the range's winner t* (minimum,
 //       later primitive on ties) is the winner under c iff t* <= c, otherwise nothing is hit (rect.rs:49-60, sphere.rs:56-74 — whose
 //       second root is never below the first —, tri.rs:24-41).
 //   (3) So leaf X contributes the function  c -> (c > t_in(X) && t*(X) <= c) ? t*(X) : c,  and after X the recursion's closest hit is at
-//       most max(t*(X), t_in(X)).  That value — from leaves EARLIER in the recursion's order only — is the bound a lane walks with: a box
-//       or primitive it rejects, the recursion rejects too (its closest hit is smaller still).  What a lane keeps of its range is the
-//       last accepted leaf (t_in, t*, primitive): an earlier accepted leaf k1 of the same lane can be forgotten when the next one, k2,
-//       has t_in(k2) < t*(k1) and t*(k2) <= t*(k1) (then k2 is accepted whenever k1 was, with the same outcome) — always true unless
-//       t*(k1) <= t_in(k1), a primitive hit that rounding put in front of its own box, and k2 falls into that one-ulp gap: the lane
-//       then raises `dirty`, and the ray is walked again by the plain loop (never observed to matter; counted in stats[13]).
-//   (4) At the end the ray's owner folds the kept leaves of its ranges in the recursion's order — its own range's first, exact because
-//       that range walked with the true closest hit, then along the `next` links — with exactly the comparison of (3).
+//       most max(t*(X), t_in(X)).  That value — from leaves EARLIER in the recursion's order only: the ray's t_max at the tree's door and
+//       the lane's own accepted leaves — is the bound a lane walks with: a box or primitive it rejects, the recursion rejects too (its
+//       closest hit is smaller still).  What a lane keeps of its range is the last accepted leaf (t_in, t*, primitive): an earlier
+//       accepted leaf k1 of the same lane can be forgotten when the next one, k2, has t_in(k2) < t*(k1) and t*(k2) <= t*(k1) (then k2 is
+//       accepted whenever k1 was, with the same outcome) — always true unless t*(k1) <= t_in(k1), a primitive hit that rounding put in
+//       front of its own box, and k2 falls into that one-ulp gap: the lane then raises `dirty`, and the ray is walked again by the
+//       plain loop (counted in stats[13]).
+//   (4) At the end the ray's owner folds the kept leaves of its group in the recursion's order — its own range's first, exact because
+//       that range walked with the true closest hit, then lane 1, 2, ... of the group — with exactly the comparison of (3).
 // Rays that are not tame (NaNs possible) and near-first order do not take this path.
-#ifndef RT_COOP_MIN_FREE
-#define RT_COOP_MIN_FREE 2u      // a hand-over round (about two box steps' worth of cross-lane traffic) needs at least this many idle lanes
+#ifndef RT_COOP_MAX_LANES
+#define RT_COOP_MAX_LANES 8u     // lanes per ray at most (the owner included); the cut has 16 subtrees at most
 #endif
 DEV uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
 DEV uint32_t fperm(uint32_t dst_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst_lane << 2), (int)v); }
@@ -1343,105 +1347,80 @@ DEV float bperm(uint32_t src_lane, float x) { return __uint_as_float(bperm(src_l
 template <typename T> DEV V3<T> bperm3(uint32_t s, V3<T> v) { return mk<T>(bperm(s, v.x), bperm(s, v.y), bperm(s, v.z)); }
 struct CoopStats { unsigned long long steps, step_lanes, splits, fallbacks; };
 
-// All 64 lanes call this together (uniform control flow).  `enter`: this lane's ray r walks the tree at `root` and is offered
-// [t_min, t_max]; the others lend their lanes.  Returns (for entering lanes) whether something was hit, t_out / prim_out as bvh_hit_ww;
-// `redo` comes back set for an entering lane whose result must be recomputed by the plain walk (see (3) above).
+// All 64 lanes call this together (uniform control flow).  `enter`: this lane's ray r walks the tree of BVH object `ob` and is offered
+// [t_min, t_max]; the others lend their lanes.  The caller guarantees 1 <= (entering lanes) <= 32.  Returns (for entering lanes) whether
+// something was hit, t_out / prim_out as bvh_hit_ww; `redo` comes back set for an entering lane whose result must be recomputed by the
+// plain walk (see (3) above).  (Every cross-lane read is executed by all lanes: a lane switched off by a branch reads as 0.)
 template <typename T, uint32_t FEATS>
-DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, uint32_t root, const RayT<T>& r, T t_min, T t_max, T& t_out, uint32_t& prim_out,
+DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t_out, uint32_t& prim_out,
                       bool& redo, CoopStats& cs) {
-    const uint32_t NONE = 0xFFFFFFFFu, NO_LANE = 0xFFu;
-    RayT<T> w = r;                                        // the ray this lane walks for: its own, or (after a hand-over) a borrowed copy
-    V3<T> inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
-    T bound = t_max;                                      // >= the recursion's closest hit at every node of this lane's range
-    uint32_t node = enter ? root : NONE, end = NONE;      // the range still to walk: [node, end) in the recursion's order
-    uint32_t cand = NONE;                                 // right child of the inner node entered most recently without a hand-over since
-    T k_tin = T(0), k_t = T(0); uint32_t k_prim = NONE;   // the leaf this lane keeps: its box's t_in, its winner (t*, primitive)
-    uint32_t next = NO_LANE, prev = NO_LANE;              // the lanes that walk the range following / preceding this one (same ray)
-    bool lent = false, dirty = false, have_leaf = false;
-    bool head = enter;                                    // walks the FIRST range of its own ray: bound is the true closest hit
+    const uint32_t NONE = 0xFFFFFFFFu, DIRTY = 0xFFFFFFFEu;
+    // ---- the groups (everything here is wave-uniform or a rank)
+    const unsigned long long em = __ballot(enter);
+    const uint32_t nE = (uint32_t)__popcll(em), nF = 64u - nE;
+    uint32_t k = 1u + nF / nE; if (k > RT_COOP_MAX_LANES) k = RT_COOP_MAX_LANES;      // lanes per ray, the owner included: 2 .. 8
+    const uint32_t kh = k - 1u;                                                        // helpers per ray
+    const uint32_t inv_kh = (65536u + kh - 1u) / kh, inv_k = (65536u + k - 1u) / k;    // x / kh == (x * inv_kh) >> 16 for the x < 128 used here
+    const uint32_t rp = lane_rank(em), rf = lane - rp;                                 // rank among the entering lanes / among the others
+    const bool helper = !enter && rf < nE * kh;
+    const uint32_t orank = (rf * inv_kh) >> 16;                                        // helper: its owner's rank, its place in the group (1 .. kh)
+    const uint32_t place = enter ? 0u : 1u + rf - orank * kh;
+    // two stable partitions of the lane ids (a permutation each: no two lanes send to one)
+    const uint32_t e_at = fperm(enter ? rp : nE + rf, lane);                           // lane j < nE holds the id of the j-th entering lane
+    const uint32_t f_at = fperm(enter ? nF + rp : rf, lane);                           // lane j < nF holds the id of the j-th other lane
+    const uint32_t my_owner = bperm(helper ? orank : 0u, e_at);
+    const uint32_t src = helper ? my_owner : lane;                                     // (everyone else reads its own registers back)
+    RayT<T> w;                                                                         // the ray this lane walks for: its own, or its owner's
+    w.o = bperm3(src, r.o); w.d = bperm3(src, r.d);
+    w.tm = (FEATS & F_SPHERES) ? bperm(src, r.tm) : r.tm;                              // (only moving spheres read the ray's time)
+    T bound = bperm(src, t_max);                                                       // >= the recursion's closest hit at every node of this lane's range
+    const V3<T> inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
+    // ---- this lane's range: subtrees [place S / k, (place + 1) S / k) of the cut
+    const uint32_t* F = P.bvh_frontier + ob.pad0 * RT_FRONTIER_STRIDE;
+    const uint32_t S = cl(F);
+    const uint32_t fa = (place * S * inv_k) >> 16, fb = ((place + 1u) * S * inv_k) >> 16;
+    const bool walks = (enter || helper) && fa < fb;
+    uint32_t node = walks ? cl(F + 1u + fa) : NONE;
+    const uint32_t end = (walks && fb < S) ? cl(F + 1u + fb) : NONE;                   // [node, end) in the recursion's order
+    T k_tin = T(0), k_t = T(0); uint32_t k_prim = NONE;                                // the leaf this lane keeps: its box's t_in, its winner (t*, primitive)
+    bool dirty = false, have_leaf = false;
+    cs.splits += nE * kh;
     for (;;) {
         for (;;) {
             const bool want_box = node != NONE && !have_leaf;
             const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
             if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
+            auto box_step = [&]() {
+                const DBvhNode<T> nd = fetch_node(P, node);
+                const bool inside = box_inside_tame(nd, w.o, inv, t_min, bound);
+                if (inside && (nd.a & BVH_LEAF)) have_leaf = true;                     // the leaf stays the lane's node until the leaf step has tested it
+                else { node = inside ? nd.c : nd.skip; if (node == end) node = NONE; }
+            };
+            cs.steps++; cs.step_lanes += n_box;
+            if (want_box) box_step();
 #pragma unroll
-            for (int k = 0; k < RT_BOX_STEPS; k++) {
-                const bool go = node != NONE && !have_leaf;
-                cs.steps++; cs.step_lanes += (unsigned long long)__popcll(__ballot(go));
-                if (go) {
-                    const DBvhNode<T> nd = fetch_node(P, node);
-                    const bool inside = box_inside_tame(nd, w.o, inv, t_min, bound);
-                    const bool leaf = (nd.a & BVH_LEAF) != 0u;
-                    if (inside && leaf) have_leaf = true;                 // the leaf stays the lane's node until the leaf step has tested it
-                    else {
-                        if (inside && cand == NONE) cand = nd.b;          // [nd.b, end) can go to a helper while this lane walks [nd.c, nd.b)
-                        node = inside ? nd.c : nd.skip;
-                        if (node == cand) cand = NONE;                    // arrived there itself
-                        if (node == end) node = NONE;
-                    }
-                }
+            for (int q = 1; q < RT_BOX_STEPS; q++) {
+                const bool more = node != NONE && !have_leaf;
+                cs.steps++; cs.step_lanes += (unsigned long long)__popcll(__ballot(more));
+                if (more) box_step();
             }
-            // ---- hand-over round: lanes holding a range to give away meet lanes with nothing to do
-            const bool is_giver = cand != NONE && node != NONE;
-            // (a) a helper whose range is finished and left nothing — typically the right sibling's box failed at once — goes back to work
-            //     for its chain predecessor: same ray, and the new range [cand, end of the giver) ends where the helper's old one began, so
-            //     the chain's order holds.  Four values cross lanes, the ray stays where it is.
-            const bool spent = lent && node == NONE && k_prim == NONE && !have_leaf;
-            bool gave = false;
-            if (__ballot(spent) != 0ull && __ballot(is_giver && next != NO_LANE) != 0ull) {
-                const uint32_t nx = next != NO_LANE ? next : lane;
-                const bool regive = is_giver && next != NO_LANE && bperm(nx, spent ? 1u : 0u) != 0u;
-                const uint32_t pv = spent ? prev : lane;
-                const uint32_t p_cand = bperm(pv, regive ? cand : NONE), p_end = bperm(pv, end);
-                const T p_bound = bperm(pv, bound);
-                if (spent && p_cand != NONE) { node = p_cand; end = p_end; bound = p_bound; if (node == end) node = NONE; }      // (prev(next(G)) == G always)
-                if (regive) { end = cand; gave = true; cs.splits++; }
-            }
-            // (b) the others meet lanes that have not walked for anybody yet
-            const bool idle = node == NONE && k_prim == NONE && next == NO_LANE && !lent && !head;
-            const bool idle_head = head && node == NONE && k_prim == NONE && next == NO_LANE;      // an owner that is finished without a hit
-            const bool is_free = idle || idle_head;
-            const bool want = is_giver && !gave;
-            const unsigned long long Gm = __ballot(want), Fm = __ballot(is_free);
-            const uint32_t nG = (uint32_t)__popcll(Gm), nF = (uint32_t)__popcll(Fm);
-            if (nG != 0u && nF >= RT_COOP_MIN_FREE) {
-                const uint32_t kk = nG < nF ? nG : nF;
-                const uint32_t rg = lane_rank(Gm), rf = lane_rank(Fm);
-                // two stable partitions of the lane ids: givers first / free lanes first (a permutation each: no two lanes send to one)
-                const uint32_t g_at = fperm(want ? rg : nG + (lane - rg), lane);           // lane j < nG holds the j-th giver's id
-                const uint32_t f_at = fperm(is_free ? rf : nF + (lane - rf), lane);        // lane j < nF holds the j-th free lane's id
-                const uint32_t my_helper = bperm(rg, f_at), my_src = bperm(rf, g_at);
-                const bool give = want && rg < kk, take = is_free && rf < kk;
-                // the giver's old successor learns its new predecessor (prev(next(G)) == G stays true)
-                const uint32_t pv = prev != NO_LANE ? prev : lane;
-                const uint32_t p_helper = bperm(pv, give ? my_helper : NO_LANE);
-                if (prev != NO_LANE && p_helper != NO_LANE) prev = p_helper;
-                const uint32_t s = take ? my_src : lane;                                   // (everyone else reads its own registers back)
-                w.o = bperm3(s, w.o); w.d = bperm3(s, w.d); inv = bperm3(s, inv);
-                if (FEATS & F_SPHERES) w.tm = bperm(s, w.tm);                               // (only moving spheres read the ray's time)
-                bound = bperm(s, bound);
-                const uint32_t src_cand = bperm(s, cand), src_end = bperm(s, end), src_next = bperm(s, next);
-                if (take) { node = src_cand; end = src_end; next = src_next; prev = my_src; lent = true; head = false; if (node == end) node = NONE; }
-                if (give) { end = cand; next = my_helper; }
-                cs.splits += kk;
-            }
-            cand = NONE;            // (a range offered in this round and not taken is not offered again: the lane has walked on since)
         }
         if (have_leaf) {
             const DBvhNode<T> lf = fetch_node(P, node);
             T t; uint32_t prim;
             if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, w, t_min, bound, t, prim)) {
-                // t_in of the leaf's own box, as AABB::hit computes it (box_inside_tame)
-                const T ax = (lf.mn[0] - w.o.x) * inv.x, bx = (lf.mx[0] - w.o.x) * inv.x;
-                const T ay = (lf.mn[1] - w.o.y) * inv.y, by = (lf.mx[1] - w.o.y) * inv.y;
-                const T az = (lf.mn[2] - w.o.z) * inv.z, bz = (lf.mx[2] - w.o.z) * inv.z;
-                const T tin = max_nn(max_nn(max_nn(min_nn(ax, bx), t_min), min_nn(ay, by)), min_nn(az, bz));
-                if (head) bound = t;                                   // the first range IS the recursion: closest = t (hit.rs:62-69)
+                if (enter) bound = t;                                  // the first range IS the recursion: closest = t (hit.rs:62-69)
                 else {
+                    // t_in of the leaf's own box, as AABB::hit computes it (box_inside_tame)
+                    const T ax = (lf.mn[0] - w.o.x) * inv.x, bx = (lf.mx[0] - w.o.x) * inv.x;
+                    const T ay = (lf.mn[1] - w.o.y) * inv.y, by = (lf.mx[1] - w.o.y) * inv.y;
+                    const T az = (lf.mn[2] - w.o.z) * inv.z, bz = (lf.mx[2] - w.o.z) * inv.z;
+                    const T tin = max_nn(max_nn(max_nn(min_nn(ax, bx), t_min), min_nn(ay, by)), min_nn(az, bz));
                     if (k_prim != NONE && !(tin < k_t && t <= k_t)) dirty = true;
                     bound = t > tin ? t : tin;
+                    k_tin = tin;
                 }
-                k_tin = tin; k_t = t; k_prim = prim;
+                k_t = t; k_prim = prim;
             }
             node = lf.skip;
             if (node == end) node = NONE;
@@ -1449,25 +1428,23 @@ DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, uint32_t r
         }
         if (__ballot(node != NONE) == 0ull) break;
     }
-    // ---- the owner folds the kept leaves of its ray's ranges, in the recursion's order
-    T c = t_max; uint32_t rp = NONE; bool any = false, bad = false;
-    const bool own = enter && !lent;                       // (an owner that lent its lane had finished without a hit and without helpers)
-    if (own && k_prim != NONE) { c = k_t; rp = k_prim; any = true; }
-    uint32_t cur = own ? next : NO_LANE;
-    while (__ballot(cur != NO_LANE) != 0ull) {
-        const bool on = cur != NO_LANE;
-        const uint32_t s = on ? cur : lane;
-        const T h_tin = bperm(s, k_tin), h_t = bperm(s, k_t);
-        const uint32_t h_prim = bperm(s, k_prim), h_link = bperm(s, next | (dirty ? 0x100u : 0u));
-        if (on) {
-            if (h_prim != NONE && c > h_tin && h_t <= c) { c = h_t; rp = h_prim; any = true; }
-            if (h_link & 0x100u) bad = true;
-            cur = h_link & 0xFFu;
+    // ---- the owner folds the kept leaves of its group, in the recursion's order
+    T c = t_max; uint32_t rp_out = NONE; bool any = false, bad = false;
+    if (enter && k_prim != NONE) { c = k_t; rp_out = k_prim; any = true; }
+    const uint32_t pub_prim = dirty ? DIRTY : k_prim;
+    for (uint32_t q = 0; q < kh; q++) {
+        const uint32_t h_lane = bperm(enter ? rp * kh + q : 0u, f_at);
+        const uint32_t s2 = enter ? h_lane : lane;
+        const T h_tin = bperm(s2, k_tin), h_t = bperm(s2, k_t);
+        const uint32_t h_prim = bperm(s2, pub_prim);
+        if (enter) {
+            if (h_prim == DIRTY) bad = true;
+            else if (h_prim != NONE && c > h_tin && h_t <= c) { c = h_t; rp_out = h_prim; any = true; }
         }
     }
     redo = bad;
-    if (bad) cs.fallbacks++;
-    t_out = c; prim_out = rp;
+    cs.fallbacks += (unsigned long long)__popcll(__ballot(bad));
+    t_out = c; prim_out = rp_out;
     return any;
 }
 
@@ -1489,13 +1466,18 @@ DEV bool world_hit_coop(const KParams<T>& P, uint32_t lane, bool act, const RayT
         const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
         const bool tame = P.bvh_tame != 0u && __ballot(act && !ray_is_tame(r.o, inv)) == 0ull;
         T t = T(0); uint32_t prim = 0; bool hit = false;
-        if (tame) {
+        // AABB::hit of the tree's root is what BVH::hit does first (bvh.rs:78): who enters?  Nobody: nothing to do.  More than half of the
+        // wave: there is no lane to spare per ray and the plain walk is the loop.  Otherwise every entering ray gets a group of lanes.
+        const bool pass = act && box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest);
+        const uint32_t n_pass = (uint32_t)__popcll(__ballot(pass));
+        if (n_pass == 0u) continue;
+        if (tame && n_pass <= 32u) {
             bool redo = false;
-            hit = bvh_hit_coop<T, FEATS>(P, lane, act, ob.geom_first, r, t_min, closest, t, prim, redo, cs);
+            hit = bvh_hit_coop<T, FEATS>(P, lane, pass, ob, r, t_min, closest, t, prim, redo, cs);
             if (__ballot(redo) != 0ull) {                    // (see bvh_hit_coop (3): the plain walk for those rays)
-                if (act && redo) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
+                if (pass && redo) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
             }
-        } else if (act) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
+        } else if (pass) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
         if (act && hit) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     }
     t_hit = closest;

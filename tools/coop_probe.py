@@ -26,16 +26,24 @@ for name in names:
           f'hand-overs {ts["leaf_steps"]}, redone rays {ts["leaf_lanes"]}', flush=True)
     W = H = 400; spp = 64
     res = {}
-    for tag, fl in (('default', 0), ('lockstep', R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH), ('coop', R.RT_LOCKSTEP_BVH | R.RT_COOP_BVH)):
+    levels = os.environ.get('COOP_LEVELS', '').split(',') if os.environ.get('COOP_LEVELS') else [None]
+    cases = [('default', 0, None), ('lockstep', R.RT_LOCKSTEP_BVH | R.RT_NO_SPECULATE_BVH, None)] + [('coop' if lv is None else f'coop L{lv}', R.RT_LOCKSTEP_BVH | R.RT_COOP_BVH, lv) for lv in levels]
+    for tag, fl, lv in cases:
+        if lv is not None: os.environ['RT_COOP_LEVELS'] = lv
+        else: os.environ.pop('RT_COOP_LEVELS', None)
         ms = []
         for _ in range(3):
             out = R.render(b, cam, bg, W, H, spp, 50, flags=fl)
             ms.append(R.last_kernel_ms(b))
         res[tag] = (min(ms), out)
         extra = ''
-        if tag == 'coop':
+        if tag.startswith('coop'):
             ts = R.last_traversal_stats(b)
-            extra = f'  steps {ts["traversal_steps"]}, lanes/step {ts["traversal_lanes"] / max(1, ts["traversal_steps"]):.1f}, hand-overs {ts["leaf_steps"]}, redone {ts["leaf_lanes"]}'
+            extra = f'  steps {ts["traversal_steps"]}, lanes/step {ts["traversal_lanes"] / max(1, ts["traversal_steps"]):.1f}, hand-overs {ts["leaf_steps"]}, redone+regives {ts["leaf_lanes"]}'
+            import ctypes as C
+            cyc = (C.c_ulonglong * 8)(); be.lib.rt_debug_section_cycles.argtypes = [C.c_void_p, C.c_void_p]; be.lib.rt_debug_section_cycles(b.h, cyc)
+            if cyc[0]: extra += f'\n      per round: walking {cyc[1] / cyc[0]:.1f}, finished with a leaf {cyc[2] / cyc[0]:.1f}, spent helpers {cyc[3] / cyc[0]:.1f}, never used {cyc[4] / cyc[0]:.1f}, givers {cyc[5] / cyc[0]:.1f} (rounds {cyc[0]})'
         print(f'    {tag:9s} {min(ms):8.3f} ms  {W * H * spp / min(ms) / 1e3:8.1f} Msamples/s{extra}', flush=True)
-    d = np.abs(res['coop'][1] - res['lockstep'][1]); fin = np.isfinite(d)
-    print(f'    frame sums coop vs lockstep: max |diff| {d[fin].max():.3e}, non-finite pattern equal: {bool(np.array_equal(np.isfinite(res["coop"][1]), np.isfinite(res["lockstep"][1])))}')
+    last = [t for t in res if t.startswith('coop')][-1]
+    d = np.abs(res[last][1] - res['lockstep'][1]); fin = np.isfinite(d)
+    print(f'    frame sums coop vs lockstep: max |diff| {d[fin].max():.3e}, non-finite pattern equal: {bool(np.array_equal(np.isfinite(res[last][1]), np.isfinite(res["lockstep"][1])))}')

@@ -77,7 +77,7 @@ template <typename T, typename K> int run(K kern, const char* name, const char* 
     const double ns = (double)ms * 1e6 / ops;                   // kernel time (HIP events) per operation per SIMD
     const double cyc = ns * ghz;                                // ... in shader-clock cycles
     const double cyc_wave = (double)mx / ops;                   // cross-check: the slowest wave's own s_memtime span
-    printf("%s,%s,%d,%.3f,%.3f,%.3f,%.3f,%.3f\n", name, what, iters, ms, ns, ghz, cyc, cyc_wave);
+    printf("%s,\"%s\",%d,%.3f,%.3f,%.3f,%.3f,%.3f\n", name, what, iters, ms, ns, ghz, cyc, cyc_wave);
     (void)hipFree(d); (void)hipFree(dt); return 0;
 }
 int main() {
