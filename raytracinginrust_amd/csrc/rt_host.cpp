@@ -555,6 +555,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.bvh_frontier = (const uint32_t*)d.frontier;
+    { bool ok = true; for (const DRect<double>& rc : f.rects) for (double v : {rc.k, rc.a0, rc.a1, rc.b0, rc.b1}) ok = ok && std::fabs(v) < 1e90; P.rects_tame = ok ? 1u : 0u; }
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
         const double big = sizeof(T) == 8 ? 1e300 : 1e30;

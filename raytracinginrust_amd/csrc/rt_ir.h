@@ -121,6 +121,7 @@ template <typename T> struct KParams {
     const uint32_t* bvh_frontier;  // cooperative BVH walk: per BVH object (DObject::pad0 = its index) RT_FRONTIER_STRIDE words: [0] = S, the number of
                                    // subtrees its tree is cut into at depth RT_FRONTIER_DEPTH (a leaf above that depth is one of them), [1 .. S] their
                                    // root nodes in the recursion's order: subtree j is the node range [F[j], F[j + 1]) of the threaded walk
+    uint32_t rects_tame;           // every rect's k, a0, a1, b0, b1 is finite and below 2^300 in magnitude (the -DRT_RECIP_RECTS measurement build's guard)
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 

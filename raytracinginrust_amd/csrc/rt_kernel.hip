@@ -250,6 +250,54 @@ template <typename T> DEV bool rect_test_axes(const DRect<T>& r, T ok, T dk, T o
     t_out = t;
     return true;
 }
+// Measurement build (-DRT_RECIP_RECTS): the 18 divisions (k - o_k) / d_k of a Cornell bounce have nine distinct denominators.
+// The denominator's half of the hardware's division sequence — v_rcp_f64 and two Newton steps — is computed once per ray and space
+// (refined_rcp); a quotient then is n * r, one residual, one correction, v_div_fixup (div_by).  Bit for bit the compiler's expansion of
+// n / d whenever v_div_scale_f64 leaves both operands unscaled, which it does for 2^-300 <= |d| <= 2^300 and 2^-722 <= |n| < 2^301; a
+// smaller |n| (with such a d) gives |t| < 2^-400 by either route — below every t_min of the path, the test rejects it either way — and
+// n = 0 gives the same signed zero (v_div_fixup looks at the original operands).  `safe` is wave-uniform: every lane's d and o in range
+// and every rect's k finite below 2^300 (KParams::rects_tame); otherwise the plain division runs.
+#ifndef RT_RECIP_RECTS
+#define RT_RECIP_RECTS 0
+#endif
+DEV double refined_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    return r;
+}
+DEV float refined_rcp(float d) { return 1.0f / d; }
+DEV double div_by(double n, double d, double r) {
+    const double q = n * r;
+    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, q, n), r, q), d, n);
+}
+DEV float div_by(float n, float d, float) { return n / d; }
+DEV bool recip_safe(double x) { const uint32_t e = ((uint32_t)((unsigned long long)__double_as_longlong(x) >> 52)) & 0x7FFu; return e - 723u <= 600u; }   // 2^-300 <= |x| < 2^301
+DEV bool recip_safe(float) { return false; }
+DEV bool below_2_300(double x) { return ((((uint32_t)((unsigned long long)__double_as_longlong(x) >> 52)) & 0x7FFu) < 1323u); }
+DEV bool below_2_300(float) { return false; }
+template <typename T> struct Recip { V3<T> r; bool safe; };      // refined reciprocals of a ray's direction; safe: wave-uniform
+template <typename T> DEV Recip<T> make_recip(const RayT<T>& ray, bool rects_tame) {
+    Recip<T> q;
+    const bool ok = recip_safe(ray.d.x) && recip_safe(ray.d.y) && recip_safe(ray.d.z) && below_2_300(ray.o.x) && below_2_300(ray.o.y) && below_2_300(ray.o.z);
+    q.safe = rects_tame && __ballot(!ok) == 0ull;
+    q.r = mk<T>(refined_rcp(ray.d.x), refined_rcp(ray.d.y), refined_rcp(ray.d.z));
+    return q;
+}
+template <typename T> DEV bool rect_test_axes_rr(const DRect<T>& r, T ok, T dk, T rk, T oa, T da, T ob, T db, T t_min, T t_max, T& t_out) {   // rect.rs:49-60
+    T t = div_by(r.k - ok, dk, rk);
+    if (t < t_min || t > t_max) return false;
+    T a = oa + t * da;
+    T b = ob + t * db;
+    if (a < r.a0 || a > r.a1 || b < r.b0 || b > r.b1) return false;
+    t_out = t;
+    return true;
+}
+template <typename T> DEV bool rect_test_rr(const DRect<T>& r, const RayT<T>& ray, const V3<T>& rc, T t_min, T t_max, T& t_out) {
+    if (r.plane == 2u) return rect_test_axes_rr(r, ray.o.x, ray.d.x, rc.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, t_max, t_out);
+    if (r.plane == 1u) return rect_test_axes_rr(r, ray.o.y, ray.d.y, rc.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, t_max, t_out);
+    return rect_test_axes_rr(r, ray.o.z, ray.d.z, rc.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, t_max, t_out);
+}
 // The axis triple (k,a,b) of rect.rs:26-32 is chosen by a branch on `plane` rather than by per-component selects:
 // at the top level `plane` is wave-uniform (a scalar branch); in BVH leaves (cube faces) it is uniform in practice.
 template <typename T> DEV bool rect_test(const DRect<T>& r, const RayT<T>& ray, T t_min, T t_max, T& t_out) {
@@ -293,7 +341,8 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
-DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out,
+                   const Recip<T>* rc = nullptr) {
     bool any = false;
     T closest = t_max;
     if (kind == G_RECT) {
@@ -318,7 +367,7 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
                 if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)) == 0u) { atomicAdd(&P.stats[14], 1ull); if (m == 0ull) atomicAdd(&P.stats[15], 1ull); }
             }
 #endif
-            if (rect_test(cur, ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
+            if (RT_RECIP_RECTS && rc && rc->safe ? rect_test_rr(cur, ray, rc->r, t_min, closest, t) : rect_test(cur, ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
             cur = nxt;
         }
     } else if ((FEATS & F_SPHERES) && kind == G_SPHERE) {
@@ -567,20 +616,30 @@ struct HitId { uint32_t obj, prim; };   // prim: GeomKind << 28 | index, or PRIM
 static const uint32_t PRIM_MEDIUM = 0xFFFFFFFFu;
 
 template <typename T, uint32_t FEATS>
-DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack) {
+DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack, const Recip<T>* rc = nullptr) {
     if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) return bvh_hit<T, FEATS>(P, ob.geom_first, r, t_min, t_max, t, prim, stack);
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, rc);
 }
 
 // One object of the top-level list under HittableList::hit (hit.rs:59-71): offered [t_min, closest], a hit replaces the
 // running (closest, id).  ConstantMedium objects draw from the path's RNG (medium.rs:44).
 template <typename T, uint32_t FEATS>
-DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack) {
+DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack,
+                    const Recip<T>* world_rc = nullptr) {
     RayT<T> r = ray;
-    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+    bool rotated = false;                                   // (wave-uniform) a Rotate changes the direction: its own reciprocals
+    for (uint32_t k = 0; k < ob.n_ops; k++) { const DOp<T> op = ld_op(P.ops + ob.first_op + k); rotated = rotated || op.kind == OP_ROTATE; op_fwd(op, r); }
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
         T t; uint32_t prim;
-        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        bool hit;
+        if (RT_RECIP_RECTS && world_rc && ob.geom_kind == G_RECT) {
+            if (rotated) { const Recip<T> own = make_recip(r, P.rects_tame != 0u); hit = geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, &own); }
+            else {                                                                      // same direction as the world-space ray; a Translate moved the origin
+                Recip<T> own = *world_rc; own.safe = own.safe && __ballot(!(below_2_300(r.o.x) && below_2_300(r.o.y) && below_2_300(r.o.z))) == 0ull;
+                hit = geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, &own);
+            }
+        } else hit = geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack);
+        if (hit) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     } else {
         // ConstantMedium::hit, medium.rs:27-61
         T t1, t2; uint32_t p1, p2;
@@ -611,6 +670,9 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
                         // [6] / [7] lanes whose ray passes the root box of the former / latter, [8] calls, [12] lanes in the calls
     unsigned long long dg[3] = {0, 0, 0}, dl[2] = {0, 0};
 #endif
+#if RT_RECIP_RECTS
+    const Recip<T> world_rc = make_recip(ray, P.rects_tame != 0u);
+#endif
     for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
         const DObject ob = ld_obj(P.objects + oi);
 #ifdef RT_DIAG_OBJ
@@ -622,7 +684,11 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
             dl[ob.n_ops ? 1 : 0] += (unsigned long long)__popcll(__ballot(box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest)));
         }
 #endif
+#if RT_RECIP_RECTS
+        object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack, &world_rc);
+#else
         object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
+#endif
 #ifdef RT_DIAG_OBJ
         __builtin_amdgcn_sched_barrier(0); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
         dg[ob.geom_kind == G_BVH ? (ob.n_ops ? 1 : 0) : 2] += t1 - t0;
@@ -1378,10 +1444,15 @@ DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, const DObj
     // ---- this lane's range: subtrees [place S / k, (place + 1) S / k) of the cut
     const uint32_t* F = P.bvh_frontier + ob.pad0 * RT_FRONTIER_STRIDE;
     const uint32_t S = cl(F);
+    const uint32_t F_lane = cl(F + 1u + (lane & 15u));                                 // the cut's nodes, one per lane (one load, no dependent second one)
     const uint32_t fa = (place * S * inv_k) >> 16, fb = ((place + 1u) * S * inv_k) >> 16;
     const bool walks = (enter || helper) && fa < fb;
-    uint32_t node = walks ? cl(F + 1u + fa) : NONE;
-    const uint32_t end = (walks && fb < S) ? cl(F + 1u + fb) : NONE;                   // [node, end) in the recursion's order
+    const uint32_t F_a = bperm(fa & 15u, F_lane), F_b = bperm(fb & 15u, F_lane);
+    uint32_t node = walks ? F_a : NONE;
+    const uint32_t end = (walks && fb < S) ? F_b : NONE;                               // [node, end) in the recursion's order
+    // the lanes of the group that walk the range before this one / the first one: their bounds are bounds for this lane too (see (3))
+    const uint32_t h_prev = bperm(helper && place >= 2u ? rf - 1u : 0u, f_at);         // the helper one place earlier (free-lane rank rf - 1)
+    const uint32_t pred_lane = !helper ? lane : (place == 1u ? my_owner : h_prev);
     T k_tin = T(0), k_t = T(0); uint32_t k_prim = NONE;                                // the leaf this lane keeps: its box's t_in, its winner (t*, primitive)
     bool dirty = false, have_leaf = false;
     cs.splits += nE * kh;
@@ -1425,6 +1496,11 @@ DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, const DObj
             node = lf.skip;
             if (node == end) node = NONE;
             have_leaf = false;
+        }
+        {   // after a leaf step: what the owner and the lane one place earlier have found bounds this lane's range too (they walk earlier
+            // ranges of the same ray) — a hit of the owner's prunes its helpers at once, the others' hits travel down the group
+            const T b_own = bperm(helper ? my_owner : lane, bound), b_pred = bperm(pred_lane, bound);
+            if (helper) { bound = b_own < bound ? b_own : bound; bound = b_pred < bound ? b_pred : bound; }
         }
         if (__ballot(node != NONE) == 0ull) break;
     }
@@ -1471,7 +1547,10 @@ DEV bool world_hit_coop(const KParams<T>& P, uint32_t lane, bool act, const RayT
         const bool pass = act && box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest);
         const uint32_t n_pass = (uint32_t)__popcll(__ballot(pass));
         if (n_pass == 0u) continue;
-        if (tame && n_pass <= 32u) {
+#ifndef RT_COOP_LIMIT
+#define RT_COOP_LIMIT 32u
+#endif
+        if (tame && n_pass <= RT_COOP_LIMIT) {
             bool redo = false;
             hit = bvh_hit_coop<T, FEATS>(P, lane, pass, ob, r, t_min, closest, t, prim, redo, cs);
             if (__ballot(redo) != 0ull) {                    // (see bvh_hit_coop (3): the plain walk for those rays)
@@ -1868,6 +1947,9 @@ template <typename T, typename F, typename L> static auto dispatch(uint32_t scen
         if (co) return f(std::integral_constant<uint32_t, FEATS_MESH | F_COOP>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
+    // (no triangles, plain lock-step loop in the reference's order — the final scene: the triangle arms are compiled out.  *Measured* round 4:
+    // 114 instead of 137 spill instructions, 120 instead of 132 bytes of scratch per lane; see DESIGN.md for what it gains.)
+    if ((scene_feats & ~(FEATS_NO_PBR & ~(uint32_t)F_TRIS)) == 0u && !nf && !ps && !co && !(flags & 1024u)) return f(std::integral_constant<uint32_t, FEATS_NO_PBR & ~(uint32_t)F_TRIS>());
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
         if (co) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_COOP>());
         if ((flags & 1024u) && !nf && !ps && !co) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH

@@ -2,7 +2,7 @@
 usage: RT_WORKLOADS=C2,C3,C1 python tools/diag_sections.py [spp]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/ab/diag.so')
+os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/abx/diag.so')
 import torch
 from PIL import Image
 from raytracinginrust_amd import _lib, render as R, scenes, workloads
