@@ -51,10 +51,6 @@ enum {
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
-    RT_COOP_BVH = 256,     /* scheduling only, same samples (lock-step BVH kernels, reference order): a BVH object is walked by all 64 lanes of the
-                              wavefront together — lanes whose rays do not enter it take over the far half of an entering lane's remaining
-                              range of the recursion (rt_kernel.hip: bvh_hit_coop; ray state stays in registers) ...                    */
-    RT_NO_COOP_BVH = 512,  /* ... and this one forces it off                                                                      */
     RT_SPECULATE_BVH = 1024, /* scheduling only, same samples (lock-step BVH kernel): a lane that has reached a leaf walks on while it waits for the
                               leaf step (rt_kernel.hip: bvh_hit_spec).  Chosen automatically for scenes whose world is one BVH (every ray
                               enters it); this flag forces it on ...                                                          */

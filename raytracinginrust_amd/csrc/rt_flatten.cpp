@@ -399,25 +399,6 @@ void relayout_bvh_by_depth(HostFlat& f) {
     }
     f.bvh.swap(out);
     for (DObject& ob : f.objects) if (ob.geom_kind == G_BVH) ob.geom_first = new_id[ob.geom_first];
-    // The cut of every tree at depth RT_FRONTIER_DEPTH, in the recursion's order (left before right): the cooperative walk deals these
-    // subtrees to the lanes of a ray's group (rt_kernel.hip: bvh_hit_coop)
-    f.bvh_frontier.clear();
-    uint32_t n_trees = 0;
-    for (DObject& ob : f.objects) if (ob.geom_kind == G_BVH) {
-        ob.pad0 = n_trees++;
-        std::vector<uint32_t> rec(RT_FRONTIER_STRIDE, DONE);
-        uint32_t S = 0;
-        struct Item { uint32_t id, d; };
-        std::vector<Item> st; st.push_back({ob.geom_first, 0u});
-        while (!st.empty()) {
-            const Item it = st.back(); st.pop_back();
-            const DBvhNode<double>& nd = f.bvh[it.id];
-            if ((nd.a & BVH_LEAF) || it.d == RT_FRONTIER_DEPTH) { rec[1 + S++] = it.id; continue; }
-            st.push_back({nd.b, it.d + 1u}); st.push_back({nd.c, it.d + 1u});      // left (c) is popped first
-        }
-        rec[0] = S;
-        f.bvh_frontier.insert(f.bvh_frontier.end(), rec.begin(), rec.end());
-    }
 }
 
 } // namespace

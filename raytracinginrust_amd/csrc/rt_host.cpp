@@ -33,7 +33,7 @@ static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_er
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> static void free_device_scene(DeviceScene<T>& d) {
     free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
-    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.frontier); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
+    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
     d.valid = false;
 }
 
@@ -411,7 +411,6 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
     if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
     if (upload_raw(f.lights, d.lights)) return -1;
-    if (upload_raw(f.bvh_frontier, d.frontier)) return -1;
     std::vector<DPerlin<T>> pl(s.perlins.size());
     for (size_t i = 0; i < pl.size(); i++) {
         for (int k = 0; k < 768; k++) pl[i].rd_vec[k] = (T)s.perlins[i].rd_vec[k];
@@ -503,19 +502,13 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
         if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size()) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
-    // Lane-cooperative BVH walk (scheduling only, rt_kernel.hip: bvh_hit_coop): the reference-order lock-step kernels of scenes without the
-    // principled material
-    {
-        const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
-        if (!can || (flags & RT_NO_COOP_BVH)) out &= ~(uint32_t)RT_COOP_BVH;
-    }
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
     // enters it, which is where walking on past an untested leaf pays (*measured* random spheres +2.6 %; scenes whose trees few lanes
     // enter lose 3 %)
     {
         const bool one_bvh = f.objects.size() == 1 && f.objects[0].geom_kind == G_BVH && f.objects[0].medium < 0;
         const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u &&
-                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH | RT_COOP_BVH));
+                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
         if (can && one_bvh && !(flags & RT_NO_SPECULATE_BVH)) out |= RT_SPECULATE_BVH;
         if (!can || (flags & RT_NO_SPECULATE_BVH)) out &= ~(uint32_t)RT_SPECULATE_BVH;
     }
@@ -554,8 +547,6 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.n_bvh = (uint32_t)f.bvh.size();
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
-    P.bvh_frontier = (const uint32_t*)d.frontier;
-    { bool ok = true; for (const DRect<double>& rc : f.rects) for (double v : {rc.k, rc.a0, rc.a1, rc.b0, rc.b1}) ok = ok && std::fabs(v) < 1e90; P.rects_tame = ok ? 1u : 0u; }
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
         const double big = sizeof(T) == 8 ? 1e300 : 1e30;

@@ -43,14 +43,12 @@ enum Feat : uint32_t {
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
-    F_COOP = 1u << 9,       // not a scene feature: lock-step loop whose bare BVH objects are walked by all lanes of the wave together (RT_COOP_BVH)
     F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count, node.c = rank in DFS
                                                    //       preorder (= the reference's visiting order: resolves exact-t ties in near-first mode);
                                                    // inner: node.a = split axis (0..2), node.b = right child, node.c = left child
-static const uint32_t RT_FRONTIER_DEPTH = 4u, RT_FRONTIER_STRIDE = 20u;      // 2^4 subtrees at most; one record = count + 16 node ids (+ padding to 16 bytes)
 static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
 static const int RT_MAX_BVH_DEPTH = 48;
 
@@ -61,7 +59,7 @@ template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad;
 template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
-struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };   // pad0: a BVH object's index among the BVH objects (its record in KParams::bvh_frontier)
+struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 template <typename T> struct alignas(16) DMaterial { uint32_t kind, tex; T albedo[3]; T param; };   // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
@@ -118,10 +116,6 @@ template <typename T> struct KParams {
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
     // debugging aid (-DRT_TRACE_PATH builds, rt_debug_trace_path): the path (trace_px, trace_s) writes 16 doubles per level to trace_out
     double* trace_out; uint32_t trace_px, trace_s;
-    const uint32_t* bvh_frontier;  // cooperative BVH walk: per BVH object (DObject::pad0 = its index) RT_FRONTIER_STRIDE words: [0] = S, the number of
-                                   // subtrees its tree is cut into at depth RT_FRONTIER_DEPTH (a leaf above that depth is one of them), [1 .. S] their
-                                   // root nodes in the recursion's order: subtree j is the node range [F[j], F[j + 1]) of the threaded walk
-    uint32_t rects_tame;           // every rect's k, a0, a1, b0, b1 is finite and below 2^300 in magnitude (the -DRT_RECIP_RECTS measurement build's guard)
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 

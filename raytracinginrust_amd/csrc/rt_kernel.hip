@@ -250,54 +250,6 @@ template <typename T> DEV bool rect_test_axes(const DRect<T>& r, T ok, T dk, T o
     t_out = t;
     return true;
 }
-// Measurement build (-DRT_RECIP_RECTS): the 18 divisions (k - o_k) / d_k of a Cornell bounce have nine distinct denominators.
-// The denominator's half of the hardware's division sequence — v_rcp_f64 and two Newton steps — is computed once per ray and space
-// (refined_rcp); a quotient then is n * r, one residual, one correction, v_div_fixup (div_by).  Bit for bit the compiler's expansion of
-// n / d whenever v_div_scale_f64 leaves both operands unscaled, which it does for 2^-300 <= |d| <= 2^300 and 2^-722 <= |n| < 2^301; a
-// smaller |n| (with such a d) gives |t| < 2^-400 by either route — below every t_min of the path, the test rejects it either way — and
-// n = 0 gives the same signed zero (v_div_fixup looks at the original operands).  `safe` is wave-uniform: every lane's d and o in range
-// and every rect's k finite below 2^300 (KParams::rects_tame); otherwise the plain division runs.
-#ifndef RT_RECIP_RECTS
-#define RT_RECIP_RECTS 0
-#endif
-DEV double refined_rcp(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
-    return r;
-}
-DEV float refined_rcp(float d) { return 1.0f / d; }
-DEV double div_by(double n, double d, double r) {
-    const double q = n * r;
-    return __builtin_amdgcn_div_fixup(__builtin_fma(__builtin_fma(-d, q, n), r, q), d, n);
-}
-DEV float div_by(float n, float d, float) { return n / d; }
-DEV bool recip_safe(double x) { const uint32_t e = ((uint32_t)((unsigned long long)__double_as_longlong(x) >> 52)) & 0x7FFu; return e - 723u <= 600u; }   // 2^-300 <= |x| < 2^301
-DEV bool recip_safe(float) { return false; }
-DEV bool below_2_300(double x) { return ((((uint32_t)((unsigned long long)__double_as_longlong(x) >> 52)) & 0x7FFu) < 1323u); }
-DEV bool below_2_300(float) { return false; }
-template <typename T> struct Recip { V3<T> r; bool safe; };      // refined reciprocals of a ray's direction; safe: wave-uniform
-template <typename T> DEV Recip<T> make_recip(const RayT<T>& ray, bool rects_tame) {
-    Recip<T> q;
-    const bool ok = recip_safe(ray.d.x) && recip_safe(ray.d.y) && recip_safe(ray.d.z) && below_2_300(ray.o.x) && below_2_300(ray.o.y) && below_2_300(ray.o.z);
-    q.safe = rects_tame && __ballot(!ok) == 0ull;
-    q.r = mk<T>(refined_rcp(ray.d.x), refined_rcp(ray.d.y), refined_rcp(ray.d.z));
-    return q;
-}
-template <typename T> DEV bool rect_test_axes_rr(const DRect<T>& r, T ok, T dk, T rk, T oa, T da, T ob, T db, T t_min, T t_max, T& t_out) {   // rect.rs:49-60
-    T t = div_by(r.k - ok, dk, rk);
-    if (t < t_min || t > t_max) return false;
-    T a = oa + t * da;
-    T b = ob + t * db;
-    if (a < r.a0 || a > r.a1 || b < r.b0 || b > r.b1) return false;
-    t_out = t;
-    return true;
-}
-template <typename T> DEV bool rect_test_rr(const DRect<T>& r, const RayT<T>& ray, const V3<T>& rc, T t_min, T t_max, T& t_out) {
-    if (r.plane == 2u) return rect_test_axes_rr(r, ray.o.x, ray.d.x, rc.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, t_max, t_out);
-    if (r.plane == 1u) return rect_test_axes_rr(r, ray.o.y, ray.d.y, rc.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, t_max, t_out);
-    return rect_test_axes_rr(r, ray.o.z, ray.d.z, rc.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, t_max, t_out);
-}
 // The axis triple (k,a,b) of rect.rs:26-32 is chosen by a branch on `plane` rather than by per-component selects:
 // at the top level `plane` is wave-uniform (a scalar branch); in BVH leaves (cube faces) it is uniform in practice.
 template <typename T> DEV bool rect_test(const DRect<T>& r, const RayT<T>& ray, T t_min, T t_max, T& t_out) {
@@ -341,8 +293,7 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
-DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out,
-                   const Recip<T>* rc = nullptr) {
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
     bool any = false;
     T closest = t_max;
     if (kind == G_RECT) {
@@ -367,7 +318,7 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
                 if (__builtin_amdgcn_mbcnt_hi((uint32_t)(ex >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ex, 0u)) == 0u) { atomicAdd(&P.stats[14], 1ull); if (m == 0ull) atomicAdd(&P.stats[15], 1ull); }
             }
 #endif
-            if (RT_RECIP_RECTS && rc && rc->safe ? rect_test_rr(cur, ray, rc->r, t_min, closest, t) : rect_test(cur, ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
+            if (rect_test(cur, ray, t_min, closest, t)) { closest = t; prim_out = (G_RECT << 28) | i; any = true; }
             cur = nxt;
         }
     } else if ((FEATS & F_SPHERES) && kind == G_SPHERE) {
@@ -616,30 +567,20 @@ struct HitId { uint32_t obj, prim; };   // prim: GeomKind << 28 | index, or PRIM
 static const uint32_t PRIM_MEDIUM = 0xFFFFFFFFu;
 
 template <typename T, uint32_t FEATS>
-DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack, const Recip<T>* rc = nullptr) {
+DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack) {
     if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) return bvh_hit<T, FEATS>(P, ob.geom_first, r, t_min, t_max, t, prim, stack);
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, rc);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim);
 }
 
 // One object of the top-level list under HittableList::hit (hit.rs:59-71): offered [t_min, closest], a hit replaces the
 // running (closest, id).  ConstantMedium objects draw from the path's RNG (medium.rs:44).
 template <typename T, uint32_t FEATS>
-DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack,
-                    const Recip<T>* world_rc = nullptr) {
+DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack) {
     RayT<T> r = ray;
-    bool rotated = false;                                   // (wave-uniform) a Rotate changes the direction: its own reciprocals
-    for (uint32_t k = 0; k < ob.n_ops; k++) { const DOp<T> op = ld_op(P.ops + ob.first_op + k); rotated = rotated || op.kind == OP_ROTATE; op_fwd(op, r); }
+    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
         T t; uint32_t prim;
-        bool hit;
-        if (RT_RECIP_RECTS && world_rc && ob.geom_kind == G_RECT) {
-            if (rotated) { const Recip<T> own = make_recip(r, P.rects_tame != 0u); hit = geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, &own); }
-            else {                                                                      // same direction as the world-space ray; a Translate moved the origin
-                Recip<T> own = *world_rc; own.safe = own.safe && __ballot(!(below_2_300(r.o.x) && below_2_300(r.o.y) && below_2_300(r.o.z))) == 0ull;
-                hit = geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, &own);
-            }
-        } else hit = geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack);
-        if (hit) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     } else {
         // ConstantMedium::hit, medium.rs:27-61
         T t1, t2; uint32_t p1, p2;
@@ -670,9 +611,6 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
                         // [6] / [7] lanes whose ray passes the root box of the former / latter, [8] calls, [12] lanes in the calls
     unsigned long long dg[3] = {0, 0, 0}, dl[2] = {0, 0};
 #endif
-#if RT_RECIP_RECTS
-    const Recip<T> world_rc = make_recip(ray, P.rects_tame != 0u);
-#endif
     for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
         const DObject ob = ld_obj(P.objects + oi);
 #ifdef RT_DIAG_OBJ
@@ -684,11 +622,7 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
             dl[ob.n_ops ? 1 : 0] += (unsigned long long)__popcll(__ballot(box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest)));
         }
 #endif
-#if RT_RECIP_RECTS
-        object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack, &world_rc);
-#else
         object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
-#endif
 #ifdef RT_DIAG_OBJ
         __builtin_amdgcn_sched_barrier(0); const unsigned long long t1 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0);
         dg[ob.geom_kind == G_BVH ? (ob.n_ops ? 1 : 0) : 2] += t1 - t0;
@@ -1368,201 +1302,6 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
     if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], n_active); }      // (both wave-uniform: kept in scalar registers)
 }
 
-// ------------------------------------------------------------------ lane-cooperative BVH walk (F_COOP instantiations, RT_COOP_BVH)
-// A BVH object that stands beside others is entered by a minority of a wave's lanes (*measured*, round 3: 12 of 59 for the final scene's
-// sphere cluster, 27 for its ground boxes, 26 of 63 for the teapot), which then walk a hundred nodes while the others wait.  Here the
-// waiting lanes WALK FOR THEM.  The threaded preorder walk of a ray is a sequence of nodes; the flattener cuts every tree at depth
-// RT_FRONTIER_DEPTH into S <= 16 subtrees F[0] .. F[S-1] in the recursion's order (KParams::bvh_frontier), subtree j being the
-// contiguous piece [F[j], F[j+1]) of that sequence.  A ray that enters the tree gets a group of k lanes — its own and k - 1 of the
-// lanes whose rays do not enter — and lane i of the group walks the subtrees [i S / k, (i + 1) S / k): one contiguous range [node, end)
-// each, all at the same time.  Ray state never leaves registers: a helper takes a copy of the ray with sixteen cross-lane register
-// reads (ds_bpermute) once per walk, nothing goes through memory, and the step loop is the plain walk's plus one compare.
-//
-// Exactness.  BVH::hit (bvh.rs:77-91) offers every node [t_min, closest-so-far]; a later range cannot know the hits of an earlier one, so
-// it walks with a BOUND instead: a value that is provably >= the closest hit the recursion holds when it reaches any node of the range.
-//   (1) Containment: a child's box lies inside its parent's (aabb.rs:40-51) and subtraction, multiplication by 1/d, min and max are
-//       monotonic, so a node's slab interval [t_in, t_far] lies inside every ancestor's — in floating point.  Hence the recursion tests
-//       the primitives of leaf X exactly when X's OWN box passes with the closest hit c it holds then: c > t_in(X) (and t_far(X) >
-//       t_in(X), which does not depend on c), and it tests them with t_max = c.  (So a range may start below the root without testing
-//       the boxes above it: they only ever cull.)
-//   (2) A leaf's primitives tested with any t_max >= c give the recursion's answer once compared with c: the range's winner t* (minimum,
-//       later primitive on ties) is the winner under c iff t* <= c, otherwise nothing is hit (rect.rs:49-60, sphere.rs:56-74 — whose
-//       second root is never below the first —, tri.rs:24-41).
-//   (3) So leaf X contributes the function  c -> (c > t_in(X) && t*(X) <= c) ? t*(X) : c,  and after X the recursion's closest hit is at
-//       most max(t*(X), t_in(X)).  That value — from leaves EARLIER in the recursion's order only: the ray's t_max at the tree's door and
-//       the lane's own accepted leaves — is the bound a lane walks with: a box or primitive it rejects, the recursion rejects too (its
-//       closest hit is smaller still).  What a lane keeps of its range is the last accepted leaf (t_in, t*, primitive): an earlier
-//       accepted leaf k1 of the same lane can be forgotten when the next one, k2, has t_in(k2) < t*(k1) and t*(k2) <= t*(k1) (then k2 is
-//       accepted whenever k1 was, with the same outcome) — always true unless t*(k1) <= t_in(k1), a primitive hit that rounding put in
-//       front of its own box, and k2 falls into that one-ulp gap: the lane then raises `dirty`, and the ray is walked again by the
-//       plain loop (counted in stats[13]).
-//   (4) At the end the ray's owner folds the kept leaves of its group in the recursion's order — its own range's first, exact because
-//       that range walked with the true closest hit, then lane 1, 2, ... of the group — with exactly the comparison of (3).
-// Rays that are not tame (NaNs possible) and near-first order do not take this path.
-#ifndef RT_COOP_MAX_LANES
-#define RT_COOP_MAX_LANES 8u     // lanes per ray at most (the owner included); the cut has 16 subtrees at most
-#endif
-DEV uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
-DEV uint32_t fperm(uint32_t dst_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst_lane << 2), (int)v); }
-DEV double bperm(uint32_t src_lane, double x) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    const uint32_t lo = bperm(src_lane, (uint32_t)u), hi = bperm(src_lane, (uint32_t)(u >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-DEV float bperm(uint32_t src_lane, float x) { return __uint_as_float(bperm(src_lane, __float_as_uint(x))); }
-template <typename T> DEV V3<T> bperm3(uint32_t s, V3<T> v) { return mk<T>(bperm(s, v.x), bperm(s, v.y), bperm(s, v.z)); }
-struct CoopStats { unsigned long long steps, step_lanes, splits, fallbacks; };
-
-// All 64 lanes call this together (uniform control flow).  `enter`: this lane's ray r walks the tree of BVH object `ob` and is offered
-// [t_min, t_max]; the others lend their lanes.  The caller guarantees 1 <= (entering lanes) <= 32.  Returns (for entering lanes) whether
-// something was hit, t_out / prim_out as bvh_hit_ww; `redo` comes back set for an entering lane whose result must be recomputed by the
-// plain walk (see (3) above).  (Every cross-lane read is executed by all lanes: a lane switched off by a branch reads as 0.)
-template <typename T, uint32_t FEATS>
-DEV bool bvh_hit_coop(const KParams<T>& P, uint32_t lane, bool enter, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t_out, uint32_t& prim_out,
-                      bool& redo, CoopStats& cs) {
-    const uint32_t NONE = 0xFFFFFFFFu, DIRTY = 0xFFFFFFFEu;
-    // ---- the groups (everything here is wave-uniform or a rank)
-    const unsigned long long em = __ballot(enter);
-    const uint32_t nE = (uint32_t)__popcll(em), nF = 64u - nE;
-    uint32_t k = 1u + nF / nE; if (k > RT_COOP_MAX_LANES) k = RT_COOP_MAX_LANES;      // lanes per ray, the owner included: 2 .. 8
-    const uint32_t kh = k - 1u;                                                        // helpers per ray
-    const uint32_t inv_kh = (65536u + kh - 1u) / kh, inv_k = (65536u + k - 1u) / k;    // x / kh == (x * inv_kh) >> 16 for the x < 128 used here
-    const uint32_t rp = lane_rank(em), rf = lane - rp;                                 // rank among the entering lanes / among the others
-    const bool helper = !enter && rf < nE * kh;
-    const uint32_t orank = (rf * inv_kh) >> 16;                                        // helper: its owner's rank, its place in the group (1 .. kh)
-    const uint32_t place = enter ? 0u : 1u + rf - orank * kh;
-    // two stable partitions of the lane ids (a permutation each: no two lanes send to one)
-    const uint32_t e_at = fperm(enter ? rp : nE + rf, lane);                           // lane j < nE holds the id of the j-th entering lane
-    const uint32_t f_at = fperm(enter ? nF + rp : rf, lane);                           // lane j < nF holds the id of the j-th other lane
-    const uint32_t my_owner = bperm(helper ? orank : 0u, e_at);
-    const uint32_t src = helper ? my_owner : lane;                                     // (everyone else reads its own registers back)
-    RayT<T> w;                                                                         // the ray this lane walks for: its own, or its owner's
-    w.o = bperm3(src, r.o); w.d = bperm3(src, r.d);
-    w.tm = (FEATS & F_SPHERES) ? bperm(src, r.tm) : r.tm;                              // (only moving spheres read the ray's time)
-    T bound = bperm(src, t_max);                                                       // >= the recursion's closest hit at every node of this lane's range
-    const V3<T> inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
-    // ---- this lane's range: subtrees [place S / k, (place + 1) S / k) of the cut
-    const uint32_t* F = P.bvh_frontier + ob.pad0 * RT_FRONTIER_STRIDE;
-    const uint32_t S = cl(F);
-    const uint32_t F_lane = cl(F + 1u + (lane & 15u));                                 // the cut's nodes, one per lane (one load, no dependent second one)
-    const uint32_t fa = (place * S * inv_k) >> 16, fb = ((place + 1u) * S * inv_k) >> 16;
-    const bool walks = (enter || helper) && fa < fb;
-    const uint32_t F_a = bperm(fa & 15u, F_lane), F_b = bperm(fb & 15u, F_lane);
-    uint32_t node = walks ? F_a : NONE;
-    const uint32_t end = (walks && fb < S) ? F_b : NONE;                               // [node, end) in the recursion's order
-    // the lanes of the group that walk the range before this one / the first one: their bounds are bounds for this lane too (see (3))
-    const uint32_t h_prev = bperm(helper && place >= 2u ? rf - 1u : 0u, f_at);         // the helper one place earlier (free-lane rank rf - 1)
-    const uint32_t pred_lane = !helper ? lane : (place == 1u ? my_owner : h_prev);
-    T k_tin = T(0), k_t = T(0); uint32_t k_prim = NONE;                                // the leaf this lane keeps: its box's t_in, its winner (t*, primitive)
-    bool dirty = false, have_leaf = false;
-    cs.splits += nE * kh;
-    for (;;) {
-        for (;;) {
-            const bool want_box = node != NONE && !have_leaf;
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
-            if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
-            auto box_step = [&]() {
-                const DBvhNode<T> nd = fetch_node(P, node);
-                const bool inside = box_inside_tame(nd, w.o, inv, t_min, bound);
-                if (inside && (nd.a & BVH_LEAF)) have_leaf = true;                     // the leaf stays the lane's node until the leaf step has tested it
-                else { node = inside ? nd.c : nd.skip; if (node == end) node = NONE; }
-            };
-            cs.steps++; cs.step_lanes += n_box;
-            if (want_box) box_step();
-#pragma unroll
-            for (int q = 1; q < RT_BOX_STEPS; q++) {
-                const bool more = node != NONE && !have_leaf;
-                cs.steps++; cs.step_lanes += (unsigned long long)__popcll(__ballot(more));
-                if (more) box_step();
-            }
-        }
-        if (have_leaf) {
-            const DBvhNode<T> lf = fetch_node(P, node);
-            T t; uint32_t prim;
-            if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, w, t_min, bound, t, prim)) {
-                if (enter) bound = t;                                  // the first range IS the recursion: closest = t (hit.rs:62-69)
-                else {
-                    // t_in of the leaf's own box, as AABB::hit computes it (box_inside_tame)
-                    const T ax = (lf.mn[0] - w.o.x) * inv.x, bx = (lf.mx[0] - w.o.x) * inv.x;
-                    const T ay = (lf.mn[1] - w.o.y) * inv.y, by = (lf.mx[1] - w.o.y) * inv.y;
-                    const T az = (lf.mn[2] - w.o.z) * inv.z, bz = (lf.mx[2] - w.o.z) * inv.z;
-                    const T tin = max_nn(max_nn(max_nn(min_nn(ax, bx), t_min), min_nn(ay, by)), min_nn(az, bz));
-                    if (k_prim != NONE && !(tin < k_t && t <= k_t)) dirty = true;
-                    bound = t > tin ? t : tin;
-                    k_tin = tin;
-                }
-                k_t = t; k_prim = prim;
-            }
-            node = lf.skip;
-            if (node == end) node = NONE;
-            have_leaf = false;
-        }
-        {   // after a leaf step: what the owner and the lane one place earlier have found bounds this lane's range too (they walk earlier
-            // ranges of the same ray) — a hit of the owner's prunes its helpers at once, the others' hits travel down the group
-            const T b_own = bperm(helper ? my_owner : lane, bound), b_pred = bperm(pred_lane, bound);
-            if (helper) { bound = b_own < bound ? b_own : bound; bound = b_pred < bound ? b_pred : bound; }
-        }
-        if (__ballot(node != NONE) == 0ull) break;
-    }
-    // ---- the owner folds the kept leaves of its group, in the recursion's order
-    T c = t_max; uint32_t rp_out = NONE; bool any = false, bad = false;
-    if (enter && k_prim != NONE) { c = k_t; rp_out = k_prim; any = true; }
-    const uint32_t pub_prim = dirty ? DIRTY : k_prim;
-    for (uint32_t q = 0; q < kh; q++) {
-        const uint32_t h_lane = bperm(enter ? rp * kh + q : 0u, f_at);
-        const uint32_t s2 = enter ? h_lane : lane;
-        const T h_tin = bperm(s2, k_tin), h_t = bperm(s2, k_t);
-        const uint32_t h_prim = bperm(s2, pub_prim);
-        if (enter) {
-            if (h_prim == DIRTY) bad = true;
-            else if (h_prim != NONE && c > h_tin && h_t <= c) { c = h_t; rp_out = h_prim; any = true; }
-        }
-    }
-    redo = bad;
-    cs.fallbacks += (unsigned long long)__popcll(__ballot(bad));
-    t_out = c; prim_out = rp_out;
-    return any;
-}
-
-// world.hit (main.rs:48, hit.rs:59-71) with every lane of the wave present: `act` lanes search, the others lend their lanes to the
-// cooperative walk of bare BVH objects.  Same objects in the same order with the same [t_min, closest] as world_hit.
-template <typename T, uint32_t FEATS>
-DEV bool world_hit_coop(const KParams<T>& P, uint32_t lane, bool act, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack, CoopStats& cs) {
-    T closest = Lim<T>::inf();
-    bool any = false;
-    for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
-        const DObject ob = ld_obj(P.objects + oi);
-        if (!(ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0))) {
-            if (act) object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
-            continue;
-        }
-        RayT<T> r = ray;
-        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
-        if (!act) { r.o = mk<T>(T(0), T(0), T(0)); r.d = mk<T>(T(1.0), T(1.0), T(1.0)); }       // (lanes without a path: a tame ray)
-        const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
-        const bool tame = P.bvh_tame != 0u && __ballot(act && !ray_is_tame(r.o, inv)) == 0ull;
-        T t = T(0); uint32_t prim = 0; bool hit = false;
-        // AABB::hit of the tree's root is what BVH::hit does first (bvh.rs:78): who enters?  Nobody: nothing to do.  More than half of the
-        // wave: there is no lane to spare per ray and the plain walk is the loop.  Otherwise every entering ray gets a group of lanes.
-        const bool pass = act && box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest);
-        const uint32_t n_pass = (uint32_t)__popcll(__ballot(pass));
-        if (n_pass == 0u) continue;
-#ifndef RT_COOP_LIMIT
-#define RT_COOP_LIMIT 32u
-#endif
-        if (tame && n_pass <= RT_COOP_LIMIT) {
-            bool redo = false;
-            hit = bvh_hit_coop<T, FEATS>(P, lane, pass, ob, r, t_min, closest, t, prim, redo, cs);
-            if (__ballot(redo) != 0ull) {                    // (see bvh_hit_coop (3): the plain walk for those rays)
-                if (pass && redo) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
-            }
-        } else if (pass) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
-        if (act && hit) { closest = t; id.obj = oi; id.prim = prim; any = true; }
-    }
-    t_hit = closest;
-    return any;
-}
-
 // ------------------------------------------------------------------ list scenes: lock-step bounce loop
 // Every iteration: dead lanes regenerate, then all 64 lanes run one level of ray_color together (closest hit over the
 // wave-uniform object list, hit record, material).  Used when the scene has no BVH: every lane's closest-hit search costs
@@ -1582,8 +1321,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0;
-    constexpr bool COOP = (FEATS & F_COOP) != 0u;       // bare BVH objects are walked by the whole wave together (bvh_hit_coop)
-    CoopStats cs; cs.steps = cs.step_lanes = cs.splits = cs.fallbacks = 0ull;
     DIAG_DECL
 
     for (;;) {
@@ -1610,16 +1347,14 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_ADD(1);
 
         // ---- one level of ray_color (main.rs:41-120) for every live lane
-        T t_hit = T(0); HitId id; id.obj = 0; id.prim = 0;
-        bool any_hit = false;
-        if (COOP) any_hit = world_hit_coop<T, FEATS>(P, lane, alive && depth_left != 0u, ray, TMin<T>::v(), rng, t_hit, id, stack, cs);   // main.rs:48, every lane present
         if (alive) {
             bool done = false;
             V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
             if (depth_left == 0) {
                 done = true;                            // main.rs:42-45
             } else {
-                if (!COOP) any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
+                T t_hit; HitId id; id.obj = 0; id.prim = 0;
+                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
                 DIAG_ADD(2);
                 if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
@@ -1654,7 +1389,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
     write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
-    if (COOP && st && lane == 0) { atomicAdd(&st[9], cs.steps); atomicAdd(&st[10], cs.step_lanes); atomicAdd(&st[12], cs.splits); atomicAdd(&st[13], cs.fallbacks); }
 #ifdef RT_DIAG
     if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
@@ -1940,19 +1674,13 @@ template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<do
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
-    const bool co = (flags & 256u) && (scene_feats & F_BVH) && !nf && !ps;      // RT_COOP_BVH (reference-order lock-step family)
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
-        if (co) return f(std::integral_constant<uint32_t, FEATS_MESH | F_COOP>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
-    // (no triangles, plain lock-step loop in the reference's order — the final scene: the triangle arms are compiled out.  *Measured* round 4:
-    // 114 instead of 137 spill instructions, 120 instead of 132 bytes of scratch per lane; see DESIGN.md for what it gains.)
-    if ((scene_feats & ~(FEATS_NO_PBR & ~(uint32_t)F_TRIS)) == 0u && !nf && !ps && !co && !(flags & 1024u)) return f(std::integral_constant<uint32_t, FEATS_NO_PBR & ~(uint32_t)F_TRIS>());
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
-        if (co) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_COOP>());
-        if ((flags & 1024u) && !nf && !ps && !co) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
+        if ((flags & 1024u) && !nf && !ps) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
     }

@@ -34,7 +34,6 @@ struct HostFlat {             // canonical f64 flattening
     std::vector<DLight> lights;
     uint32_t feats = 0;
     uint32_t bvh_depth = 0;
-    std::vector<uint32_t> bvh_frontier;         // RT_FRONTIER_STRIDE words per BVH object (KParams::bvh_frontier)
     bool bvh_tame = true;          // all BVH boxes finite, |.| < 1e300 (1e30 matters for the f32 variant: checked there too), min <= max
 };
 
@@ -42,7 +41,7 @@ template <typename T> struct DeviceScene {   // device copies of HostFlat for on
     bool valid = false;
     void* objects = nullptr; void* ops = nullptr; void* rects = nullptr; void* spheres = nullptr; void* mspheres = nullptr;
     void* tris = nullptr; void* bvh = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
-    void* lights = nullptr; void* frontier = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr;
+    void* lights = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr;
 };
 
 struct Scene {

@@ -33,18 +33,16 @@ print(f'seeds {first}..{first + n - 1}: {n_samples} samples, {n_bad_total} diver
 # mesh rooms (the persistent-traversal kernel): both loop shapes against each other (bit for bit) and against the oracle
 from test_parity_gpu import _mesh_room
 nm = int(sys.argv[3]) if len(sys.argv) > 3 else 100
-bad_bits = 0; worst_m = 0.0; div_m = 0; bad_defer = 0
+bad_bits = 0; worst_m = 0.0; div_m = 0
 for seed in range(first, first + nm):
     b, cam, bg = _mesh_room(pbe, seed)
     _, lock = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
     _, pers = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_PERSISTENT_BVH, want_samples=True)
     bad_bits += int((lock.view(np.uint64) != pers.view(np.uint64)).sum())
-    _, defr = R.render(b, cam, bg, W, H, spp, 16, seed=5 + seed, flags=R.RT_LOCKSTEP_BVH | R.RT_COOP_BVH, want_samples=True)      # round 4: the lane-cooperative walk
-    bad_defer += int((lock.view(np.uint64) != defr.view(np.uint64)).sum())
     ob, ocam, obg = _mesh_room(obe, seed)
     _, ref = orc.render(ob, ocam, obg, W, H, spp, 16, seed=5 + seed, want_samples=True)
     fin = np.isfinite(ref) & np.isfinite(pers)
     d = np.abs(np.where(fin, pers, 0.0) - np.where(fin, ref, 0.0))
     bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, ref, 0.0)))).any(axis=-1)
     div_m += int(bad.sum()); worst_m = max(worst_m, float(d[~bad].max()))
-print(f'mesh rooms {first}..{first + nm - 1}: persistent vs lock-step differing words {bad_bits}; cooperative walk vs lock-step differing words {bad_defer}; vs oracle {div_m} diverged samples, worst of the rest {worst_m:.3e}')
+print(f'mesh rooms {first}..{first + nm - 1}: persistent vs lock-step differing words {bad_bits}; vs oracle {div_m} diverged samples, worst of the rest {worst_m:.3e}')
