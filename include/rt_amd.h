@@ -51,10 +51,6 @@ enum {
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
-    RT_PAIR_BVH = 256,     /* scheduling only, same samples (lock-step BVH kernels, reference order): every ray that enters a BVH object which at most
-                              half of the wavefront enters gets a helper lane that tests the right sibling while the ray's own lane tests the
-                              left child (rt_kernel.hip: bvh_hit_pair) ...                                                              */
-    RT_NO_PAIR_BVH = 512,  /* ... and this one forces it off                                                                      */
     RT_SPECULATE_BVH = 1024, /* scheduling only, same samples (lock-step BVH kernel): a lane that has reached a leaf walks on while it waits for the
                               leaf step (rt_kernel.hip: bvh_hit_spec).  Chosen automatically for scenes whose world is one BVH (every ray
                               enters it); this flag forces it on ...                                                          */

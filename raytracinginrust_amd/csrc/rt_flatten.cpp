@@ -393,10 +393,8 @@ void relayout_bvh_by_depth(HostFlat& f) {
     for (size_t i = 0; i < n; i++) {
         DBvhNode<double> nd = f.bvh[i];
         nd.skip = skip[i] == DONE ? DONE : new_id[skip[i]];
-        // the node's depth rides on a spare byte (inner: above the split axis; leaf: above the primitive count): the pair walk keeps one
-        // bit per depth for a pre-tested right sibling (rt_kernel.hip: bvh_hit_pair)
-        if (nd.a & BVH_LEAF) { nd.c = (uint32_t)i; nd.b = (nd.b & BVH_COUNT_MASK) | (depth[i] << BVH_DEPTH_SHIFT_LEAF); }
-        else { nd.c = new_id[i + 1]; nd.b = new_id[nd.b]; nd.a = (nd.a & BVH_AXIS_MASK) | (depth[i] << BVH_DEPTH_SHIFT_INNER); }
+        if (nd.a & BVH_LEAF) nd.c = (uint32_t)i;
+        else { nd.c = new_id[i + 1]; nd.b = new_id[nd.b]; }
         out[new_id[i]] = nd;
     }
     f.bvh.swap(out);

@@ -43,15 +43,12 @@ enum Feat : uint32_t {
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
-    F_PAIR = 1u << 9,       // not a scene feature: lock-step loop in which every ray that enters a bare BVH object gets a helper lane for its right siblings (RT_PAIR_BVH)
     F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count, node.c = rank in DFS
                                                    //       preorder (= the reference's visiting order: resolves exact-t ties in near-first mode);
                                                    // inner: node.a = split axis (0..2), node.b = right child, node.c = left child
-// a node's depth below its root: inner nodes carry it above the split axis (a = axis | depth << 8), leaves above the primitive count (b = count | depth << 16)
-static const uint32_t BVH_AXIS_MASK = 0xFFu, BVH_DEPTH_SHIFT_INNER = 8u, BVH_COUNT_MASK = 0xFFFFu, BVH_DEPTH_SHIFT_LEAF = 16u;
 static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
 static const int RT_MAX_BVH_DEPTH = 48;
 
@@ -119,7 +116,6 @@ template <typename T> struct KParams {
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
     // debugging aid (-DRT_TRACE_PATH builds, rt_debug_trace_path): the path (trace_px, trace_s) writes 16 doubles per level to trace_out
     double* trace_out; uint32_t trace_px, trace_s;
-    uint32_t bvh_max_depth;        // levels of the deepest tree (the pair walk keeps one bit per level: < 32)
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 

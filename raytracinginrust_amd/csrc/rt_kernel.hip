@@ -415,7 +415,6 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
 }
 
 // `root` is the node a lane's walk starts at.
-DEV uint32_t lane_rank(unsigned long long mask);
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
     V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
@@ -450,7 +449,7 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                     if (inside && (nd.a & BVH_LEAF)) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; leaf_node = nd.c; }
                     node = (inside && !(nd.a & BVH_LEAF)) ? nd.c : nd.skip;
                 } else if (inside && !(nd.a & BVH_LEAF)) {
-                    const bool right_first = get(ray.d, nd.a & BVH_AXIS_MASK) < T(0);
+                    const bool right_first = get(ray.d, nd.a) < T(0);
                     stack[sp * 64u] = right_first ? nd.c : nd.b;           // the farther child waits
                     sp++;
                     node = right_first ? nd.b : nd.c;
@@ -461,25 +460,14 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
                 }
             };
             if (want_box) box_step();
-#ifdef RT_COUNT_STEPS   // counting build only (tools/pair_probe.py): box steps in which any lane takes part, and the lanes in them -> stats[9], [10]
-            unsigned long long cnt_steps = 1ull, cnt_lanes = n_box;
-#endif
             // further box steps under the same vote (the vote is ~30 scalar instructions and two ballots: *measured* with two steps
             // per vote random spheres +8 %, final scene +4 %); a lane that reached a leaf or the end sits them out
 #pragma unroll
-            for (int k = 1; k < RT_BOX_STEPS; k++) {
-#ifdef RT_COUNT_STEPS
-                { const unsigned long long m_ = __ballot(node != DONE && !have_leaf); if (m_) { cnt_steps++; cnt_lanes += (unsigned long long)__popcll(m_); } }
-#endif
-                if (node != DONE && !have_leaf) box_step();
-            }
-#ifdef RT_COUNT_STEPS
-            if (P.stats) { const unsigned long long ex_ = __ballot(true); if (lane_rank(ex_) == 0u) { atomicAdd(&P.stats[9], cnt_steps); atomicAdd(&P.stats[10], cnt_lanes); } }
-#endif
+            for (int k = 1; k < RT_BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
         }
         if (have_leaf) {
             T t; uint32_t prim;
-            if (range_hit<T, FEATS>(P, (leaf_a >> 28) & 7u, leaf_a & 0x0FFFFFFFu, leaf_b & BVH_COUNT_MASK, ray, t_min, closest, t, prim) &&
+            if (range_hit<T, FEATS>(P, (leaf_a >> 28) & 7u, leaf_a & 0x0FFFFFFFu, leaf_b, ray, t_min, closest, t, prim) &&
                 bvh_accept(near_first, t, closest, leaf_node, best_leaf)) { closest = t; prim_out = prim; any = true; best_leaf = leaf_node; }
             have_leaf = false;
         }
@@ -541,7 +529,7 @@ DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
             bool go = true;
             if (spec1) go = box_inside_tame(lf, ray.o, inv, t_min, closest);           // (speculation only happens on tame rays)
             T t; uint32_t prim;
-            if (go && range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b & BVH_COUNT_MASK, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
+            if (go && range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
             p1 = p2; spec1 = p2 != NONE; p2 = NONE;
         }
         if (__ballot(node != NONE || p1 != NONE) == 0ull) break;
@@ -1314,166 +1302,6 @@ DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfin
     if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], n_active); }      // (both wave-uniform: kept in scalar registers)
 }
 
-// ------------------------------------------------------------------ pair walk: a ray's right siblings are tested by a second lane (F_PAIR)
-// A BVH object that stands beside others is entered by a minority of a wave's lanes (*measured*, round 3: 12 of 59 for the final scene's
-// sphere cluster, 27 for its ground boxes, 26 of 63 for the teapot): the box tests of the walk — 25 f64 instructions each, what the
-// traversal's time is made of — are issued for a wave that is two thirds idle.  Here every entering ray gets ONE helper lane (a lane whose
-// ray does not enter; it takes a copy of the ray's origin and direction once per walk, 14 cross-lane register reads).  BVH::hit
-// (bvh.rs:77-91) tests a node's left child, walks that subtree, then tests the right child.  Whenever the owner tests a LEFT child, its
-// helper tests the right sibling in the same instruction stream, with the same (at that moment current) closest hit; the owner keeps one
-// bit per tree depth: "the right sibling at this depth has been tested", and one for the outcome.  When the walk later arrives at that
-// sibling through a skip link, no box arithmetic is needed: a failed sibling is skipped, a passed inner node is entered, a passed leaf goes
-// to the leaf step.  Arrivals are resolved in a loop of their own (one 16-byte read of the node's link words per arrival) until every
-// owner stands at a node that needs a real test, so that the expensive step is always shared by all pairs: per ray half as many box steps.
-//
-// Same result as BVH::hit, by the argument of bvh_hit_spec: (1) a box test that fails with some closest hit fails with every smaller one
-// (t_far = min(far, closest) only shrinks, t_in does not depend on it), so a sibling the helper saw fail is one the recursion culls; (2) a
-// sibling the helper saw pass with a closest hit that has shrunk since may be one the recursion culls — then, by containment (a child's
-// slab interval lies inside its parent's, in floating point: subtraction, multiplication by 1/d, min and max are monotonic), every box
-// below it fails its own exact test, and a leaf that was only pre-tested is re-tested against its own box with the closest hit as it is
-// when its turn comes, before any of its primitives; (3) left children and nodes reached without a pre-test are tested when the recursion
-// tests them, with the closest hit the recursion holds.  Hence the same primitives are tested with the same t_max in the same order.
-// Tame rays only (no NaN: box_inside_tame), trees less than 32 levels deep, reference order; otherwise the plain walk.
-DEV uint32_t bperm(uint32_t src_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v); }
-DEV uint32_t fperm(uint32_t dst_lane, uint32_t v) { return (uint32_t)__builtin_amdgcn_ds_permute((int)(dst_lane << 2), (int)v); }
-DEV double bperm(uint32_t src_lane, double x) {
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    const uint32_t lo = bperm(src_lane, (uint32_t)u), hi = bperm(src_lane, (uint32_t)(u >> 32));
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-DEV float bperm(uint32_t src_lane, float x) { return __uint_as_float(bperm(src_lane, __float_as_uint(x))); }
-template <typename T> DEV V3<T> bperm3(uint32_t s, V3<T> v) { return mk<T>(bperm(s, v.x), bperm(s, v.y), bperm(s, v.z)); }
-struct PairStats { unsigned long long steps, step_lanes, resolves, walks; };
-struct NodeLinks { uint32_t a, b, c, skip; };
-// the link words of a node (the last 16 bytes of its record) without its bounds
-template <typename T> DEV NodeLinks fetch_links(const KParams<T>& P, uint32_t node) {
-    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-    const uint32_t off = node * (uint32_t)sizeof(DBvhNode<T>) + (uint32_t)(6u * sizeof(T));
-    NodeLinks l;
-    if (sizeof(T) == 8) {                          // f64 records: the link words are one aligned 16-byte piece
-        u4 v;
-        if (node < P.n_cached) v = *(const u4*)(lds_raw + off);
-        else v = *(const CAS u4*)((const char*)P.bvh + (size_t)off);
-        l.a = v.x; l.b = v.y; l.c = v.z; l.skip = v.w;
-    } else {                                       // f32 records: 24 bytes of bounds in front of them
-        const uint32_t* q = node < P.n_cached ? (const uint32_t*)(lds_raw + off) : (const uint32_t*)((const char*)P.bvh + (size_t)off);
-        l.a = q[0]; l.b = q[1]; l.c = q[2]; l.skip = q[3];
-    }
-    return l;
-}
-
-// All 64 lanes call this together (uniform control flow); every cross-lane read is executed by all lanes (a lane switched off by a
-// branch reads as 0).  `enter`: this lane's ray r walks the tree at `root` and is offered [t_min, t_max]; at most 32 lanes enter.
-template <typename T, uint32_t FEATS>
-DEV bool bvh_hit_pair(const KParams<T>& P, uint32_t lane, bool enter, uint32_t root, const RayT<T>& r, T t_min, T t_max, T& t_out, uint32_t& prim_out, PairStats& ps) {
-    const uint32_t NONE = 0xFFFFFFFFu;
-    // ---- pairs: the j-th entering lane and the j-th other lane
-    const unsigned long long em = __ballot(enter);
-    const uint32_t nE = (uint32_t)__popcll(em), nF = 64u - nE;
-    const uint32_t rp = lane_rank(em), rf = lane - rp;                     // rank among the entering lanes / among the others
-    const bool helper = !enter && rf < nE;
-    const uint32_t e_at = fperm(enter ? rp : nE + rf, lane);               // lane j < nE holds the id of the j-th entering lane
-    const uint32_t f_at = fperm(enter ? nF + rp : rf, lane);               // lane j < nF holds the id of the j-th other lane
-    const uint32_t my_owner = bperm(helper ? rf : 0u, e_at), my_helper = bperm(enter ? rp : 0u, f_at);
-    const uint32_t src = helper ? my_owner : lane;                         // (everyone else reads its own registers back)
-    RayT<T> w = r;
-    w.o = bperm3(src, r.o); w.d = bperm3(src, r.d);
-    T closest = bperm(src, t_max);                                         // owner: the recursion's closest hit; helper: its owner's, as of the last leaf step
-    const V3<T> inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
-    uint32_t node = enter ? root : NONE;                                   // owner: the node the walk stands at
-    uint32_t sib = NONE;                                                   // ... and, when that node is a left child just descended to, its right sibling
-    bool arrived = false;                                                  // ... reached through a skip link: look at its pre-test bits first
-    uint32_t pre = 0u, cul = 0u;                                           // bit d: the right sibling at depth d on the current path has been tested by the helper / failed
-    bool have_leaf = false, leaf_stale = false, any = false;
-    ps.walks++;
-    for (;;) {
-        // ---- arrivals: no box arithmetic for a pre-tested sibling
-        while (__ballot(arrived && node != NONE) != 0ull) {
-            ps.resolves++;
-            if (arrived && node != NONE) {
-                const NodeLinks l = fetch_links(P, node);
-                const bool leaf = (l.a & BVH_LEAF) != 0u;
-                const uint32_t bit = 1u << (leaf ? (l.b >> BVH_DEPTH_SHIFT_LEAF) : (l.a >> BVH_DEPTH_SHIFT_INNER));
-                if (pre & bit) {
-                    pre &= ~bit;
-                    if (cul & bit) node = l.skip;                                      // the recursion's test fails too: on to where it goes next
-                    else if (leaf) { have_leaf = true; leaf_stale = true; arrived = false; }
-                    else { node = l.c; sib = l.c + 1u; arrived = false; }              // (siblings have consecutive ids: depth-ordered numbering)
-                } else arrived = false;                                                // not pre-tested (the root): a real test
-            }
-        }
-        const bool want_box = enter && node != NONE && !have_leaf;
-        const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
-        if (n_box == 0u && n_leaf == 0u) break;
-        if (n_box != 0u && n_leaf * RT_WW_DEN < (n_box + n_leaf) * RT_WW_NUM) {
-            // ---- a box step: the owners test their node, the helpers their owner's right sibling
-            const uint32_t h_node = bperm(helper ? my_owner : lane, want_box ? sib : NONE);
-            const uint32_t t_node = enter ? node : h_node;
-            const bool test = enter ? want_box : (helper && h_node != NONE);
-            ps.steps++; ps.step_lanes += (unsigned long long)__popcll(__ballot(test));
-            bool inside = false; DBvhNode<T> nd; nd.a = nd.b = nd.c = nd.skip = 0u;
-            if (test) { nd = fetch_node(P, t_node); inside = box_inside_tame(nd, w.o, inv, t_min, closest); }
-            const unsigned long long hm = __ballot(test && inside && !enter);           // the helpers whose sibling passes
-            if (want_box) {
-                const bool leaf = (nd.a & BVH_LEAF) != 0u;
-                if (sib != NONE) {
-                    const uint32_t bit = 1u << (leaf ? (nd.b >> BVH_DEPTH_SHIFT_LEAF) : (nd.a >> BVH_DEPTH_SHIFT_INNER));      // the sibling's depth is this node's
-                    pre |= bit;
-                    if ((hm >> my_helper) & 1ull) cul &= ~bit; else cul |= bit;
-                }
-                if (inside && leaf) { have_leaf = true; leaf_stale = false; }
-                else if (inside) { node = nd.c; sib = nd.c + 1u; }
-                else { node = nd.skip; sib = NONE; arrived = true; }
-            }
-            continue;
-        }
-        // ---- a leaf step (owners), then the helpers learn their owner's closest hit
-        if (have_leaf) {
-            const DBvhNode<T> lf = fetch_node(P, node);
-            const bool go = !leaf_stale || box_inside_tame(lf, w.o, inv, t_min, closest);      // (a pre-tested leaf: its own box again, with the closest hit as it is now)
-            T t; uint32_t prim;
-            if (go && range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b & BVH_COUNT_MASK, w, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
-            node = lf.skip; sib = NONE; arrived = true;
-            have_leaf = false;
-        }
-        const T c_own = bperm(helper ? my_owner : lane, closest);
-        if (helper) closest = c_own;
-    }
-    t_out = closest;
-    return any;
-}
-
-// world.hit (main.rs:48, hit.rs:59-71) with every lane of the wave present: `act` lanes search, the others lend their lanes to the pair
-// walk of bare BVH objects.  Same objects in the same order with the same [t_min, closest] as world_hit.
-template <typename T, uint32_t FEATS>
-DEV bool world_hit_pair(const KParams<T>& P, uint32_t lane, bool act, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack, PairStats& ps) {
-    T closest = Lim<T>::inf();
-    bool any = false;
-    for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
-        const DObject ob = ld_obj(P.objects + oi);
-        if (!(ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0))) {
-            if (act) object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
-            continue;
-        }
-        RayT<T> r = ray;
-        for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
-        if (!act) { r.o = mk<T>(T(0), T(0), T(0)); r.d = mk<T>(T(1.0), T(1.0), T(1.0)); }       // (lanes without a path: a tame ray)
-        const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
-        const bool tame = P.bvh_tame != 0u && P.bvh_max_depth <= 32u && __ballot(act && !ray_is_tame(r.o, inv)) == 0ull;
-        // AABB::hit of the tree's root is what BVH::hit does first (bvh.rs:78): who enters?  Nobody: nothing to do.  More than half of the
-        // wave: no lane to spare per ray, the plain walk is the loop.
-        const bool pass = act && box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest);
-        const uint32_t n_pass = (uint32_t)__popcll(__ballot(pass));
-        if (n_pass == 0u) continue;
-        T t = T(0); uint32_t prim = 0; bool hit = false;
-        if (tame && n_pass <= 32u) hit = bvh_hit_pair<T, FEATS>(P, lane, pass, ob.geom_first, r, t_min, closest, t, prim, ps);
-        else if (pass) hit = bvh_hit_ww<T, FEATS>(P, ob.geom_first, r, t_min, closest, t, prim, stack);
-        if (pass && hit) { closest = t; id.obj = oi; id.prim = prim; any = true; }
-    }
-    t_hit = closest;
-    return any;
-}
-
 // ------------------------------------------------------------------ list scenes: lock-step bounce loop
 // Every iteration: dead lanes regenerate, then all 64 lanes run one level of ray_color together (closest hit over the
 // wave-uniform object list, hit record, material).  Used when the scene has no BVH: every lane's closest-hit search costs
@@ -1493,8 +1321,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
     uint32_t n_nonfinite = 0, n_flush = 0;
     unsigned long long n_iters = 0, n_active = 0;
-    constexpr bool PAIR = (FEATS & F_PAIR) != 0u;       // every lane is present at every BVH object: the pair walk (bvh_hit_pair)
-    PairStats ps; ps.steps = ps.step_lanes = ps.resolves = ps.walks = 0ull;
     DIAG_DECL
 
     for (;;) {
@@ -1521,16 +1347,14 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_ADD(1);
 
         // ---- one level of ray_color (main.rs:41-120) for every live lane
-        T t_hit = T(0); HitId id; id.obj = 0; id.prim = 0;
-        bool any_hit = false;
-        if (PAIR) any_hit = world_hit_pair<T, FEATS>(P, lane, alive && depth_left != 0u, ray, TMin<T>::v(), rng, t_hit, id, stack, ps);   // main.rs:48, every lane present
         if (alive) {
             bool done = false;
             V3<T> e = mk<T>(T(0), T(0), T(0));          // terminal radiance of this path (times beta)
             if (depth_left == 0) {
                 done = true;                            // main.rs:42-45
             } else {
-                if (!PAIR) any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
+                T t_hit; HitId id; id.obj = 0; id.prim = 0;
+                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
                 DIAG_ADD(2);
                 if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
@@ -1565,7 +1389,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
     write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
-    if (PAIR && st && lane == 0) { atomicAdd(&st[9], ps.steps); atomicAdd(&st[10], ps.step_lanes); atomicAdd(&st[12], ps.resolves); atomicAdd(&st[13], ps.walks); }
 #ifdef RT_DIAG
     if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
@@ -1662,7 +1485,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                             if (inside && (nd.a & BVH_LEAF)) tv_have_leaf = true;
                             else tv_node = inside ? nd.c : nd.skip;
                         } else if (inside && !(nd.a & BVH_LEAF)) {
-                            const bool right_first = get(r.d, nd.a & BVH_AXIS_MASK) < T(0);
+                            const bool right_first = get(r.d, nd.a) < T(0);
                             stack[tv_sp * 64u] = right_first ? nd.c : nd.b;       // the farther child waits
                             tv_sp++;
                             tv_node = right_first ? nd.b : nd.c;
@@ -1688,9 +1511,9 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                     T t; uint32_t prim;
                     if (!near_first) {
                         const DBvhNode<T> lf = fetch_node(P, tv_node);
-                        if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b & BVH_COUNT_MASK, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; }
+                        if (range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; }
                         tv_node = lf.skip;
-                    } else if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b & BVH_COUNT_MASK, r, t_min, tv_closest, t, prim) &&
+                    } else if (range_hit<T, FEATS>(P, (tv_leaf_a >> 28) & 7u, tv_leaf_a & 0x0FFFFFFFu, tv_leaf_b, r, t_min, tv_closest, t, prim) &&
                         bvh_accept(near_first, t, tv_closest, tv_leaf_node, tv_best)) { tv_closest = t; tv_prim = prim; tv_any = true; tv_best = tv_leaf_node; }
                     tv_have_leaf = false;
                 }
@@ -1851,15 +1674,12 @@ template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<do
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
-    const bool pr = (flags & 256u) && (scene_feats & F_BVH) && !nf && !ps;      // RT_PAIR_BVH (reference-order lock-step family)
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
-        if (pr) return f(std::integral_constant<uint32_t, FEATS_MESH | F_PAIR>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
-        if (pr) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PAIR>());
         if ((flags & 1024u) && !nf && !ps) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());
