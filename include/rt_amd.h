@@ -241,7 +241,7 @@ int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const
  * that found a hit, 16 doubles at out[16 * level]: t, position[3], normal[3], front_face, object, primitive kind, primitive index,
  * material, incoming direction[3], 1.0 (a level without a hit stays all zero); rt_debug_get_trace fetches n_levels of them.  Only the
  * lock-step kernels of a -DRT_TRACE_PATH build of the library write the record (tools/mkab.sh trace "-DRT_TRACE_PATH" "-DRT_TRACE_PATH";
- * the shipped build leaves it zero) — tools/fuzz_probe.py compares it with the oracle's orc_trace_path. */
+ * the shipped build leaves it zero) — tests/sweeps/fuzz_probe.py compares it with the oracle's orc_trace_path. */
 int rt_debug_trace_path(rt_scene*, long long local_pixel, long long sample);
 int rt_debug_get_trace(rt_scene*, double* out, uint32_t n_levels);
 /* Debug/parity aid: like rt_render but also returns every sample's radiance (W*H*spp*3 doubles). */
