@@ -177,11 +177,13 @@ int rt_render_multi(rt_scene*, const rt_camera*, const double background[3], uin
                     uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
                     uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out);
 /* The same frame left in device memory: returns once every device's work is enqueued (kernels, gather, un-permute); *d_frame_out (may
- * be NULL) receives a DEVICE pointer on the first selected device to W*H*3 doubles in output order, owned by the scene and valid
- * until the next rt_render_multi* call on it.  Calls may follow each other without waiting: each device's work is ordered by its own
+ * be NULL) receives a DEVICE pointer on the first selected device to W*H*3 doubles in output order, owned by the scene.  Consecutive
+ * frames alternate between TWO such buffers, so a frame's pointer stays valid (and its pixels untouched) until the next-but-one
+ * rt_render_multi* call: a caller can read frame i while frame i + 1 is rendered.  Calls may follow each other without waiting: each device's work is ordered by its own
  * stream and the host runs at most one frame ahead, so the devices go from frame to frame without a launch gap (a frame of another
  * shape or device set first waits for the one in flight); timings are kept for the most recent frame.
- * rt_multi_sync waits for the frame; rt_multi_copy_frame waits and copies its first n_doubles doubles to host memory.
+ * rt_multi_sync waits for the frames in flight; rt_multi_copy_frame waits and copies the first n_doubles (<= W*H*3) doubles of the most
+ * recent frame to host memory.
  * rt_render_multi = rt_render_multi_device + rt_multi_copy_frame. */
 int rt_render_multi_device(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
                            uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
@@ -209,7 +211,8 @@ int rt_last_kernel_ms(rt_scene*, float* ms_out);
  * reset; waits for launches still in flight.  Launches of one scene on different streams may overlap (up to four streams; a
  * frame's drain then hides behind the next frame's start); launches on one stream are ordered by the stream. */
 int rt_kernel_time_total(rt_scene*, double* ms_total, unsigned long long* n_launches, int reset);
-/* Counters of the most recent finished launch: [0] samples whose radiance was not finite (the reference's
+/* Counters of the most recent FRAME — one launch for rt_render / rt_render_device, the N launches of an rt_render_multi* frame summed
+ * (N devices or virtual ranks) —: [0] samples whose radiance was not finite (the reference's
  * 0*inf / x/0 cases), [1] bounce-loop iterations summed over wavefronts, [2] lane-iterations
  * that carried a live path ([2] / (64*[1]) = lane utilisation). */
 int rt_last_stats(rt_scene*, unsigned long long out3[3]);
