@@ -499,7 +499,11 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
     if (!(flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) && (f.feats & F_BVH) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) == 0u) {
         size_t n_bvh_objects = 0;
         for (const DObject& ob : f.objects) n_bvh_objects += ob.geom_kind == G_BVH ? 1u : 0u;
-        if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size()) out |= RT_PERSISTENT_BVH;
+        // ... and only for trees of some size: *measured* (round 4, tools/mesh_size_probe.py: a lit room with one / two random triangle
+        // meshes, persistent vs lock-step ms) one tree of 63 / 199 / 599 / 1999 / 5999 nodes 1.24 / 1.09 / 0.99 / 0.85 / 0.80, two trees of
+        // 126 / 398 / 1198 / 3998 / 11998 nodes in all 1.73 / 1.28 / 1.14 / 1.02 / 0.86 — the pass machinery costs more than the waiting it
+        // removes while a walk is a few dozen steps.  The teapot room (one tree, 2047 nodes) keeps the persistent loop.
+        if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size() && f.bvh.size() >= 640u * n_bvh_objects * n_bvh_objects) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
