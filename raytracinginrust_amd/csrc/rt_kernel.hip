@@ -54,9 +54,6 @@
 #ifndef RT_WAVES_LEAN
 #define RT_WAVES_LEAN 4
 #endif
-#ifndef RT_QN_LEAN
-#define RT_QN_LEAN 64u
-#endif
 #ifndef RT_WAVES_BVH
 #define RT_WAVES_BVH 4
 #endif
@@ -1007,7 +1004,7 @@ template <uint32_t FEATS> struct Shape {
     static constexpr bool ONE_PER_CU = (FEATS & F_BVH) != 0u;
     static constexpr uint32_t WAVES = ONE_PER_CU ? 4u * WAVES_PER_SIMD : 4u;
     static constexpr uint32_t THREADS = 64u * WAVES;
-    static constexpr uint32_t QN_MIN = ONE_PER_CU ? 16u : RT_QN_LEAN;    // camera-path queue entries per wave: at least this, up to 64 (KParams::queue_entries)
+    static constexpr uint32_t QN_MIN = ONE_PER_CU ? 16u : 64u;    // camera-path queue entries per wave: at least this, up to 64 (KParams::queue_entries)
     typedef AccReg Acc;
 };
 
@@ -1397,191 +1394,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 #endif
 }
 
-#ifdef RT_XCHG
-// ------------------------------------------------------------------ experiment: material arms sorted over the workgroup's four waves
-// After the hit record, the scattering lanes of the 256-thread workgroup hand (n, p or d, rng, material) to an LDS slot chosen
-// by a counting sort over arm (Lambertian with the light sample, Lambertian with the cosine sample, Metal); lane g of the
-// workgroup shades slot g and writes (direction, attenuation factor, pdf, rng) back.  Three barriers per bounce.
-static constexpr uint32_t XS = 256u;
-static constexpr uint32_t XR = 10u;     // real arrays: in n, p, d; out a (over n), dir (over d), pdf; p stays for the home lane
-template <typename T> static constexpr uint32_t xchg_bytes() { return XR * XS * (uint32_t)sizeof(T) + 5u * XS * 4u + 16u; }
-DEV void wg_barrier() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-
-template <typename T, uint32_t FEATS>
-DEV void trace_lockstep_xchg(const KParams<T>& P, uint32_t lane, uint32_t wave, T* q_real, uint32_t* q_u32, unsigned char* xraw, uint32_t* stack) {
-    static_assert(FEATS == 0u, "constant textures only");
-    T* const xr = (T*)xraw;
-    uint32_t* const xu = (uint32_t*)(xraw + XR * XS * (uint32_t)sizeof(T));
-    uint32_t* const xc = xu + 5u * XS;
-    WaveWork w; w.cur_px = w.end_px = w.cur_s = w.s_lo = w.s_hi = w.cur_gp = w.cur_i = w.cur_j = w.q_head = w.q_count = 0; w.queue_done = false;
-    bool alive = false;
-    RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
-    V3<T> beta = mk<T>(T(0), T(0), T(0));
-    uint32_t depth_left = 0, path_px = 0, path_s = 0;
-    Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
-    uint32_t acc_px = NONE_PX;
-    typename Shape<FEATS>::Acc acc;
-    acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0);
-    uint32_t n_nonfinite = 0, n_flush = 0;
-    unsigned long long n_iters = 0, n_active = 0;
-    const V3<T> zero = mk<T>(T(0), T(0), T(0));
-#ifdef RT_DIAG
-    unsigned long long dg_t = 0, dg_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-
-    for (;;) {
-        DIAG_T0();
-        uint32_t new_px = 0;
-        const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, !alive, ray, rng, new_px, path_s);
-        const bool wave_idle = __ballot(alive || got_new) == 0;
-        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
-        if (got_new) {
-            if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
-            path_px = new_px;
-            beta = mk<T>(T(1.0), T(1.0), T(1.0));
-            depth_left = P.max_depth;
-            alive = true;
-        }
-        if (!wave_idle) n_iters++;
-        if (alive) n_active++;
-        DIAG_ADD(0);
-
-        uint32_t key = 0, pmat = 0;
-        V3<T> pn = zero, pp = zero;
-        if (alive) {
-            bool done = false;
-            V3<T> e = zero;
-            if (depth_left == 0) {
-                done = true;
-            } else {
-                T t_hit; HitId id; id.obj = 0; id.prim = 0;
-                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);
-                if (!any_hit) {
-                    e = ld3(P.background); done = true;
-                } else {
-                    Rec<T> rec;
-                    finalize_hit<T, FEATS>(P, ray, t_hit, id, true, rec);
-                    const DMaterial<T> mt = ld_mat(P.materials + rec.mat);
-                    if (mt.kind == M_LAMBERTIAN) key = (P.n_lights != 0u && rng_bool(rng)) ? 1u : 2u;
-                    else if (mt.kind == M_METAL) key = 3u;
-                    else if (mt.kind == M_DIFFUSE_LIGHT) { if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p); done = true; }
-                    else done = true;
-                    if (key) { pn = rec.n; pp = rec.p; pmat = rec.mat; }
-                }
-            }
-            if (done) { add_radiance(P, beta * e, acc, n_nonfinite, path_px, path_s); alive = false; }
-        }
-
-        DIAG_ADD(1);
-        // ---- counting sort over the workgroup
-        const unsigned long long m1 = __ballot(key == 1u), m2 = __ballot(key == 2u), m3 = __ballot(key == 3u);
-        if (lane == 0) xc[wave] = (uint32_t)__popcll(m1) | (uint32_t)__popcll(m2) << 10 | (uint32_t)__popcll(m3) << 20 | (wave_idle ? 1u << 30 : 0u);
-        wg_barrier();
-        DIAG_ADD(2);
-        const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)xc[0]), w1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)xc[1]);
-        const uint32_t w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)xc[2]), w3 = (uint32_t)__builtin_amdgcn_readfirstlane((int)xc[3]);
-        if ((w0 & w1 & w2 & w3) >> 30) break;                       // every wave idle: the workgroup is finished
-        const uint32_t CM = 0x3FFFFFFFu;
-        const uint32_t tot = (w0 & CM) + (w1 & CM) + (w2 & CM) + (w3 & CM);
-        const uint32_t before = (wave > 0u ? (w0 & CM) : 0u) + (wave > 1u ? (w1 & CM) : 0u) + (wave > 2u ? (w2 & CM) : 0u);
-        const uint32_t t1 = tot & 1023u, t2 = (tot >> 10) & 1023u, t3 = (tot >> 20) & 1023u;
-        uint32_t slot = 0;
-        if (key == 1u) slot = (before & 1023u) + lane_rank(m1);
-        else if (key == 2u) slot = t1 + ((before >> 10) & 1023u) + lane_rank(m2);
-        else if (key == 3u) slot = t1 + t2 + ((before >> 20) & 1023u) + lane_rank(m3);
-        if (key) {
-            xr[0u * XS + slot] = pn.x; xr[1u * XS + slot] = pn.y; xr[2u * XS + slot] = pn.z;
-            xr[3u * XS + slot] = pp.x; xr[4u * XS + slot] = pp.y; xr[5u * XS + slot] = pp.z;
-            xr[6u * XS + slot] = ray.d.x; xr[7u * XS + slot] = ray.d.y; xr[8u * XS + slot] = ray.d.z;
-            xu[0u * XS + slot] = rng.s0; xu[1u * XS + slot] = rng.s1; xu[2u * XS + slot] = rng.s2; xu[3u * XS + slot] = rng.s3;
-            xu[4u * XS + slot] = pmat;
-        }
-        DIAG_ADD(3);
-        wg_barrier();
-        DIAG_ADD(4);
-
-        // ---- lane g of the workgroup shades slot g
-        const uint32_t g = wave * 64u + lane;
-        if (g < t1 + t2 + t3) {
-            const V3<T> n = mk<T>(xr[0u * XS + g], xr[1u * XS + g], xr[2u * XS + g]);
-            const bool lamb = g < t1 + t2;
-            const uint32_t xo = lamb ? 3u * XS : 6u * XS;            // Lambertian works from the hit point, Metal from the incoming direction
-            const V3<T> x = mk<T>(xr[xo + g], xr[xo + XS + g], xr[xo + 2u * XS + g]);
-            Rng r; r.s0 = xu[0u * XS + g]; r.s1 = xu[1u * XS + g]; r.s2 = xu[2u * XS + g]; r.s3 = xu[3u * XS + g];
-            const DMaterial<T> mt = ld_mat(P.materials + xu[4u * XS + g]);
-            V3<T> dir = zero, a = zero; T pdf_value = T(1.0); uint32_t absorbed = 0u;
-            if (lamb) {                                                             // Lambertian: mat.rs:225-249, main.rs:92-98
-                V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, T(0), T(0), x);
-                Onb<T> uvw = onb_from_w(n);
-                if (P.n_lights == 0u) {
-                    dir = onb_local(uvw, random_cosine_direction<T>(r));
-                    T cosine = dot(normalized(dir), uvw.w);
-                    pdf_value = (cosine > T(0)) ? cosine / PI_T : T(0);
-                } else {
-                    if (g < t1) {
-                        uint32_t li = rng_index(r, P.n_lights);
-                        dir = light_random<T, FEATS>(P, ld_light(P.lights + li), x, r);
-                    } else {
-                        dir = onb_local(uvw, random_cosine_direction<T>(r));
-                    }
-                    T lsum = T(0);
-                    for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), x, dir);
-                    T lpdf = lsum / T(P.n_lights);
-                    T cosine = dot(normalized(dir), uvw.w);
-                    T cpdf = (cosine > T(0)) ? cosine / PI_T : T(0);
-                    pdf_value = T(0.5) * lpdf + T(0.5) * cpdf;
-                }
-                T sc = m_max(dot(n, normalized(dir)), T(0)) / PI_T;
-                a = attenuation * sc;
-            } else {                                                                // Metal: mat.rs:280-293 (x is the incoming direction)
-                V3<T> dn = x + ((-dot(x, n)) * T(2.0) * n);
-                V3<T> reflected = normalized(dn);
-                V3<T> fz = random_in_unit_sphere<T>(r);
-                V3<T> sd = reflected + mt.param * fz;
-                if (dot(sd, n) > T(0)) { a = ld3(mt.albedo); dir = sd; }
-                else absorbed = 1u;
-            }
-            xr[6u * XS + g] = dir.x; xr[7u * XS + g] = dir.y; xr[8u * XS + g] = dir.z;
-            xr[0u * XS + g] = a.x; xr[1u * XS + g] = a.y; xr[2u * XS + g] = a.z;
-            xr[9u * XS + g] = pdf_value;
-            xu[0u * XS + g] = r.s0; xu[1u * XS + g] = r.s1; xu[2u * XS + g] = r.s2; xu[3u * XS + g] = r.s3;
-            xu[4u * XS + g] = absorbed;
-        }
-        DIAG_ADD(5);
-        wg_barrier();
-        DIAG_ADD(6);
-
-        // ---- home lanes take the scattered ray back
-        // (every lane reads, slot 0 where it has nothing there: ray and rng are then dead across the shading above — a lane without a
-        // key has no path and takes a new one from the queue next)
-        ray.o = mk<T>(xr[3u * XS + slot], xr[4u * XS + slot], xr[5u * XS + slot]);
-        ray.d = mk<T>(xr[6u * XS + slot], xr[7u * XS + slot], xr[8u * XS + slot]);
-        rng.s0 = xu[0u * XS + slot]; rng.s1 = xu[1u * XS + slot]; rng.s2 = xu[2u * XS + slot]; rng.s3 = xu[3u * XS + slot];
-        if (key) {
-            bool done = xu[4u * XS + slot] != 0u;
-            if (!done) {
-                const V3<T> a = mk<T>(xr[0u * XS + slot], xr[1u * XS + slot], xr[2u * XS + slot]);
-                beta = (beta * a) / xr[9u * XS + slot];
-                depth_left--;
-                if (depth_left == 0) done = true;
-                if ((P.flags & 2u) && beta.x == T(0) && beta.y == T(0) && beta.z == T(0)) done = true;
-            }
-            if (done) { add_radiance(P, beta * zero, acc, n_nonfinite, path_px, path_s); alive = false; }
-        }
-        DIAG_ADD(7);
-    }
-    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
-    unsigned long long* const st = stats_row(P.stats);
-    unsigned long long live = n_active;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
-    write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
-#ifdef RT_DIAG
-    if (st && lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]); atomicAdd(&st[14], dg_sum[6]); atomicAdd(&st[15], dg_sum[7]); }
-#endif
-}
-#endif
-
 // ------------------------------------------------------------------ BVH scenes: resumable closest-hit search, persistent traversal
 // With a BVH in the scene the cost of `world.hit` differs wildly between lanes (a ray that misses the root box is done
 // after one node, its neighbour walks a hundred), and in lock-step every lane waits for the slowest one: *measured* VALU
@@ -1808,13 +1620,6 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     T* q_real = (T*)regen;                                         // [7][QN]: o.x o.y o.z d.x d.y d.z time
     uint32_t* q_u32 = (uint32_t*)(regen + 7u * QN * sizeof(T));    // [6][QN]: rng s0..s3, local pixel, sample
     uint32_t* stack = (uint32_t*)(lds_raw + nodes_bytes + S::WAVES * regen_bytes(QN)) + wave_in_block * (P.stack_depth * 64u) + lane;
-#ifdef RT_XCHG
-    if constexpr (FEATS == 0u) {
-        unsigned char* xraw = lds_raw + nodes_bytes + S::WAVES * regen_bytes(QN) + S::WAVES * P.stack_depth * 256u;
-        trace_lockstep_xchg<T, FEATS>(P, lane, wave_in_block, q_real, q_u32, xraw, stack);
-        return;
-    }
-#endif
     if (FEATS & F_PERSIST) trace_resumable<T, FEATS>(P, lane, q_real, q_u32, stack);
     else trace_lockstep<T, FEATS>(P, lane, q_real, q_u32, stack);
 }
@@ -1827,9 +1632,6 @@ static hipError_t allow_lds(size_t shmem) {            // more than the default 
 }
 template <typename T, uint32_t FEATS>
 static hipError_t launch_one(const KParams<T>& P, uint32_t n_blocks, size_t shmem, hipStream_t stream) {
-#ifdef RT_XCHG
-    if (FEATS == 0u) shmem += xchg_bytes<T>();
-#endif
     hipError_t e = allow_lds<T, FEATS>(shmem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((pathtrace_kernel<T, FEATS>), dim3(n_blocks), dim3(Shape<FEATS>::THREADS), shmem, stream, P);
@@ -1838,9 +1640,6 @@ static hipError_t launch_one(const KParams<T>& P, uint32_t n_blocks, size_t shme
 template <typename T, uint32_t FEATS>
 static int occupancy_one(size_t shmem) {
     int nb = 0;
-#ifdef RT_XCHG
-    if (FEATS == 0u) shmem += xchg_bytes<T>();
-#endif
     if (allow_lds<T, FEATS>(shmem) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, pathtrace_kernel<T, FEATS>, (int)Shape<FEATS>::THREADS, shmem) != hipSuccess) return 0;
     if (Shape<FEATS>::ONE_PER_CU && nb > 1) nb = 1;       // the register budget is set for exactly one such workgroup per CU
