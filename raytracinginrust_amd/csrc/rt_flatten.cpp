@@ -335,6 +335,11 @@ struct Flattener {
         f.textures = s.textures;
         for (const auto& m : f.materials) { if (m.kind == M_DIELECTRIC) f.feats |= F_DIELECTRIC; if (m.kind == M_PBR) f.feats |= F_PBR; if (m.kind == M_ISOTROPIC) f.feats |= F_MEDIUM; }
         for (const auto& t : f.textures) if (t.kind != T_CONSTANT) f.feats |= F_TEXTURES;
+        // a constant texture's colour rides in the material record too (albedo is otherwise unused by these kinds): kernels
+        // without texture arms then take it from the record they hold instead of gathering the texture record behind it
+        for (auto& m : f.materials)
+            if ((m.kind == M_LAMBERTIAN || m.kind == M_DIFFUSE_LIGHT) && m.tex < f.textures.size() && f.textures[m.tex].kind == T_CONSTANT)
+                for (int k = 0; k < 3; k++) m.albedo[k] = f.textures[m.tex].color[k];
         if (s.world < 0) return fail("world not set");
         Chain c;
         if (!emit(s.world, c, -1)) return false;

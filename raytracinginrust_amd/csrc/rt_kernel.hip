@@ -51,6 +51,23 @@
 // *Measured* (round 2, A/B in one process, with -disable-machine-licm): the lock-step BVH kernels are faster at 4 waves with a few
 // dozen spilled registers than at 3 without (random spheres +6.6 %, final scene +10 %); the persistent-traversal mesh kernel is not
 // (131 spills at 4 waves: teapot room -26 %).
+// shade_hit: Lambertian's two sampling arms and Metal share the instruction runs they have in common (round 4; samples bit-identical).
+// f64 kernels of the lean translation unit only: the f32 kernels draw one u32 per value, and in the BVH kernels the merged form moves
+// the register allocation for the worse (*measured* final scene -7 %, teapot room -3 %, random spheres -3.5 %; Cornell box +2.5 %,
+// +1.9 % without the first try of Metal's fuzz vector in the shared draws: profiles/r04_merged_arms_ab.log).
+#ifndef RT_MERGE_ARMS
+#define RT_MERGE_ARMS (RT_TU == 1)
+#endif
+// Lean kernels (list scenes): objects without wrappers test the path's own ray, `Translate(RotateY(..))` — the reference's instance idiom,
+// main.rs:300-309 — runs as straight-line code in the closest-hit search and in the hit record (anything else takes the generic
+// per-wrapper loops), constant colours come from the material record.  Samples bit-identical; *measured* Cornell box 30.9 -> 28.5 ms
+// per 800x800x256 on top of the merged arms (profiles/r04_lean_straight_ab.log).  0 = the generic loops only (A/B).
+#ifndef RT_LEAN_STRAIGHT
+#define RT_LEAN_STRAIGHT 1
+#endif
+#ifndef RT_MERGE_METAL_DRAWS
+#define RT_MERGE_METAL_DRAWS 1
+#endif
 #ifndef RT_WAVES_LEAN
 #define RT_WAVES_LEAN 4
 #endif
@@ -576,6 +593,26 @@ DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_
 // running (closest, id).  ConstantMedium objects draw from the path's RNG (medium.rs:44).
 template <typename T, uint32_t FEATS>
 DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack) {
+#if RT_LEAN_STRAIGHT
+    if (FEATS == 0u && ob.n_ops == 2u) {        // Translate(RotateY(..)), the reference's instance idiom (main.rs:300-309): straight-line code
+        const DOp<T> o0 = ld_op(P.ops + ob.first_op), o1 = ld_op(P.ops + ob.first_op + 1u);
+        if (o0.kind == OP_TRANSLATE && o1.kind == OP_ROTATE && o1.axis == 1u) {
+            RayT<T> r;
+            const V3<T> q = ray.o - mk<T>(o0.x, o0.y, o0.z);                          // translate.rs:23
+            r.o.x = o1.y * q.x - o1.x * q.z; r.o.y = q.y; r.o.z = o1.x * q.x + o1.y * q.z;           // rotate.rs:82-86
+            r.d.x = o1.y * ray.d.x - o1.x * ray.d.z; r.d.y = ray.d.y; r.d.z = o1.x * ray.d.x + o1.y * ray.d.z;
+            r.tm = ray.tm;
+            T t; uint32_t prim;
+            if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+            return;
+        }
+    }
+    if (FEATS == 0u && ob.n_ops == 0u) {        // no wrapper: test the path's own ray (no copy of it into the registers the wrappers rewrite)
+        T t; uint32_t prim;
+        if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        return;
+    }
+#endif
     RayT<T> r = ray;
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
@@ -666,6 +703,19 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         return;
     }
     RayT<T> r = ray;
+#if RT_LEAN_STRAIGHT
+    bool fused = false;
+    DOp<T> f0, f1;
+    if (FEATS == 0u && ob.n_ops == 2u) {
+        f0 = ld_op(P.ops + ob.first_op); f1 = ld_op(P.ops + ob.first_op + 1u);
+        fused = f0.kind == OP_TRANSLATE && f1.kind == OP_ROTATE && f1.axis == 1u;
+    }
+    if (fused) {
+        const V3<T> q = ray.o - mk<T>(f0.x, f0.y, f0.z);
+        r.o.x = f1.y * q.x - f1.x * q.z; r.o.y = q.y; r.o.z = f1.x * q.x + f1.y * q.z;
+        r.d.x = f1.y * ray.d.x - f1.x * ray.d.z; r.d.z = f1.x * ray.d.x + f1.y * ray.d.z;
+    } else
+#endif
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     const uint32_t kind = id.prim >> 28, idx = id.prim & 0x0FFFFFFFu;
     if (kind == G_RECT) {                                                             // rect.rs:61-79
@@ -706,6 +756,16 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         rec.mat = tr.mat;
     }
     // unwind the wrapper chain innermost -> outermost
+#if RT_LEAN_STRAIGHT
+    if (fused) {
+        rot_back(1u, f1.x, f1.y, rec.p);                                              // rotate.rs:90-104
+        V3<T> nw = rec.n;
+        rot_back(1u, f1.x, f1.y, nw);
+        set_face_normal(rec, r.d, nw);
+        rec.p = rec.p + mk<T>(f0.x, f0.y, f0.z);                                      // translate.rs:26
+        return;
+    }
+#endif
     for (int k = (int)ob.n_ops - 1; k >= 0; k--) {
         const DOp<T> op = ld_op(P.ops + ob.first_op + (uint32_t)k);
         if (op.kind == OP_TRANSLATE) {
@@ -1178,13 +1238,102 @@ DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_re
     return got_new;
 }
 
+// The colour of a Lambertian / DiffuseLight material.  The lean kernels (constant textures only) take it from the material record they
+// hold — rt_flatten.cpp copies a constant texture's colour there — instead of gathering the texture record behind it (*measured* +1.4 %
+// on the Cornell box; no gain in the BVH kernels, which keep the texture walk).
+template <typename T, uint32_t FEATS> DEV V3<T> const_or_tex(const KParams<T>& P, const DMaterial<T>& mt, const Rec<T>& rec) {
+    if (FEATS == 0u && RT_LEAN_STRAIGHT) return ld3(mt.albedo);
+    return tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+}
+// U01 / R(a,b) of rt_rng.h from a u64 that was drawn earlier (shade_hit draws for several arms at once)
+DEV double rng_u01_of(uint64_t u, double) { const uint64_t v = u >> 11; return ((double)(uint32_t)(v >> 32) * 4294967296.0 + (double)(uint32_t)v) * 0x1.0p-53; }
+DEV double rng_range_of(uint64_t u, double a, double b) {
+    double res = (__longlong_as_double((long long)(0x3FF0000000000000ULL | (u >> 12))) - 1.0) * (b - a) + a;
+    if (!(res < b)) { uint64_t bb = (uint64_t)__double_as_longlong(b); if (b > 0.0) bb -= 1; else if (b < 0.0) bb += 1; else bb = 0x8000000000000001ULL; res = __longlong_as_double((long long)bb); }
+    return res;
+}
 // ------------------------------------------------------------------ one level of ray_color after the hit: main.rs:50-116
 // In: the hit record.  In/out: ray (becomes the scattered ray), beta, rng, depth_left.  Out: done (the path ends here) and
 // e, the terminal radiance to be multiplied by beta.
 template <typename T, uint32_t FEATS>
 DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& beta, Rng& rng, uint32_t& depth_left, bool& done, V3<T>& e) {
     const DMaterial<T> mt = ld_mat(P.materials + rec.mat);
-    if (mt.kind == M_LAMBERTIAN) {                                          // mat.rs:225-249, main.rs:92-98
+    // Lambertian (its two sampling arms) and Metal in one instruction stream where they run the same instructions on their own
+    // values — per lane the operations and the draw order are exactly those of the separate arms below (bit-identical samples):
+    // (1) the first normalisation (onb.rs:10 / vec.rs:112-114 + mat.rs:285), (2) the next two u64 draws (pdf.rs:10-11 /
+    // rect.rs:104-105 / the first try of vec.rs:80); the cosine pdf is computed once for the scenes with and without lights.
+    constexpr bool MERGE = RT_MERGE_ARMS && sizeof(T) == 8u;               // (the f32 kernels draw one u32 per value)
+    const bool lam = mt.kind == M_LAMBERTIAN, met = mt.kind == M_METAL;
+    if (MERGE && (lam || met)) { if constexpr (MERGE) {
+        V3<T> unit0 = rec.n;
+        if (met) unit0 = ray.d + ((-dot(ray.d, rec.n)) * T(2.0) * rec.n);  // reflect, vec.rs:112-114
+        unit0 = normalized(unit0);
+        V3<T> attenuation = unit0;
+        Onb<T> uvw; uvw.w = unit0; uvw.u = unit0; uvw.v = unit0;
+        bool to_light = false;
+        DLight L; L.kind = 0xFFFFFFFFu; L.index = 0u;
+        if (lam) {                                                          // mat.rs:225-249, main.rs:92-98
+            attenuation = const_or_tex<T, FEATS>(P, mt, rec);
+            V3<T> a = (m_abs(uvw.w.x) > T(0.9)) ? mk<T>(T(0), T(1.0), T(0)) : mk<T>(T(1.0), T(0), T(0));   // onb.rs:8-20
+            uvw.v = normalized(cross(uvw.w, a));
+            uvw.u = cross(uvw.w, uvw.v);
+            if (P.n_lights != 0u && rng_bool(rng)) {                        // pdf.rs:167-173 (no lights: deviation D2, cosine only)
+                to_light = true;
+                L = ld_light(P.lights + rng_index(rng, P.n_lights));        // hit.rs:94-96
+            }
+        }
+#if RT_MERGE_METAL_DRAWS
+        const bool two = !to_light || L.kind == L_RECT;
+#else
+        const bool two = lam && (!to_light || L.kind == L_RECT);
+#endif
+        uint64_t b1 = 0, b2 = 0;
+        if (two) { b1 = rng_u64(rng); b2 = rng_u64(rng); }
+        if (lam) {
+            V3<T> dir;
+            if (!to_light) {                                                // random_cosine_direction, pdf.rs:8-18
+                T r1 = rng_u01_of(b1, T(0)), r2 = rng_u01_of(b2, T(0));
+                T z = rsqrt_(T(1.0) - r2);
+                T phi = T(2.0) * PI_T * r1;
+                T sn, cs; sincos_0_2pi(phi, sn, cs);
+                dir = onb_local(uvw, mk<T>(cs * rsqrt_(r2), sn * rsqrt_(r2), z));
+            } else if (L.kind == L_RECT) {                                  // rect.rs:103-111
+                const DRect<T> rc = ld_rect(P.rects + L.index);
+                uint32_t ki, ai, bi; plane_axes(rc.plane, ki, ai, bi);
+                T ra = rng_range_of(b1, rc.a0, rc.a1);
+                T rb = rng_range_of(b2, rc.b0, rc.b1);
+                V3<T> pt;
+                pt.x = ki == 0u ? rc.k : (ai == 0u ? ra : rb);
+                pt.y = ki == 1u ? rc.k : (ai == 1u ? ra : rb);
+                pt.z = ki == 2u ? rc.k : rb;
+                dir = pt - rec.p;
+            } else {
+                dir = light_random<T, FEATS>(P, L, rec.p, rng);
+            }
+            T cosine = dot(normalized(dir), uvw.w);                         // pdf.rs:131-139
+            T pdf_value = (cosine > T(0)) ? cosine / PI_T : T(0);
+            if (P.n_lights != 0u) {
+                T lsum = T(0);                                              // hit.rs:90-92
+                for (uint32_t li = 0; li < P.n_lights; li++) lsum += light_pdf_value<T, FEATS>(P, ld_light(P.lights + li), rec.p, dir);
+                T lpdf = P.n_lights == 1u ? lsum : lsum / T(P.n_lights);    // x / 1.0 is x
+                pdf_value = T(0.5) * lpdf + T(0.5) * pdf_value;             // pdf.rs:143-145
+            }
+            T sc = m_max(dot(rec.n, normalized(dir)), T(0)) / PI_T;         // scattering_pdf, mat.rs:246-249
+            beta = (beta * (attenuation * sc)) / pdf_value;                 // main.rs:97 (emitted is the literal zero here)
+            ray.o = rec.p; ray.d = dir;                                     // time unchanged
+        } else {                                                            // mat.rs:280-293
+#if RT_MERGE_METAL_DRAWS
+            V3<T> fz;                                                       // random_in_unit_sphere, vec.rs:78-85: the first try's a and b are drawn above
+            fz.x = rng_range_of(b1, T(-1.0), T(1.0)); fz.y = rng_range_of(b2, T(-1.0), T(1.0)); fz.z = rng_range(rng, T(-1.0), T(1.0));
+            while (!(dot(fz, fz) < T(1.0))) { T a = rng_range(rng, T(-1.0), T(1.0)), b = rng_range(rng, T(-1.0), T(1.0)), c = rng_range(rng, T(-1.0), T(1.0)); fz = mk<T>(a, b, c); }
+#else
+            V3<T> fz = random_in_unit_sphere<T>(rng);
+#endif
+            V3<T> sd = unit0 + mt.param * fz;
+            if (dot(sd, rec.n) > T(0)) { beta = ld3(mt.albedo) * beta; ray.o = rec.p; ray.d = sd; }   // main.rs:89-91
+            else done = true;                                               // None -> emitted = 0, main.rs:108-110
+        }
+    } } else if (lam) {                                                     // mat.rs:225-249, main.rs:92-98
         V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
         Onb<T> uvw = onb_from_w(rec.n);                                     // PDF::cosine_pdf, pdf.rs:81-85
         V3<T> dir; T pdf_value;
@@ -1209,7 +1358,7 @@ DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& 
         T sc = m_max(dot(rec.n, normalized(dir)), T(0)) / PI_T;             // scattering_pdf, mat.rs:246-249
         beta = (beta * (attenuation * sc)) / pdf_value;                     // main.rs:97 (emitted is the literal zero here)
         ray.o = rec.p; ray.d = dir;                                         // time unchanged
-    } else if (mt.kind == M_METAL) {                                        // mat.rs:280-293
+    } else if (met) {                                                       // mat.rs:280-293
         V3<T> dn = ray.d + ((-dot(ray.d, rec.n)) * T(2.0) * rec.n);         // reflect, vec.rs:112-114
         V3<T> reflected = normalized(dn);
         V3<T> fz = random_in_unit_sphere<T>(rng);
@@ -1261,7 +1410,7 @@ DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& 
         beta = (beta * f) / pdf_value;                                      // main.rs:104
         ray.o = rec.p; ray.d = dir;
     } else if (mt.kind == M_DIFFUSE_LIGHT) {                                // mat.rs:395-401; no scatter -> main.rs:108-110
-        if (rec.front) e = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
+        if (rec.front) e = const_or_tex<T, FEATS>(P, mt, rec);
         done = true;
     } else if ((FEATS & F_MEDIUM) && (P.flags & 4u) && mt.kind == M_ISOTROPIC) {   // RT_ISOTROPIC_SCATTER (opt-in, non-reference):
         V3<T> attenuation = tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);     // the old Isotropic::scatter, mat.rs:418-421

@@ -157,3 +157,80 @@ def test_random_scene_parity(pbe, obe, earth, seed):
     bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, rs_, 0.0)))).any(axis=-1)
     assert bad.sum() <= 2, f"seed {seed}: {int(bad.sum())} of {W * H * spp} samples diverged; first at {np.argwhere(bad)[:3].tolist()}"
     assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+
+
+def _rand_list_scene(be, seed):
+    """A list scene (no BVH, no sphere, constant textures, Lambertian / Metal / DiffuseLight): what the lean kernels serve — their
+    straight-line paths for wrapper-less objects and for `Translate(RotateY(..))`, the generic wrapper loops for every other chain,
+    the merged Lambertian / Metal arms with 0, 1 or 2 lights.  (rt_kernel.hip: RT_LEAN_STRAIGHT, RT_MERGE_ARMS.)"""
+    rs = np.random.RandomState(9000 + seed)
+    b = SceneBuilder(be)
+
+    def col(lo=0.05, hi=0.95):
+        return tuple(float(x) for x in rs.uniform(lo, hi, 3))
+
+    def material():
+        k = rs.randint(0, 4)
+        if k <= 1:
+            return b.Lambertian(b.ConstantTexture(col()))
+        if k == 2:
+            return b.Metal(col(0.4, 1.0), float(rs.choice([0.0, 0.1, 0.5, 1.0])))
+        return b.DiffuseLight(b.ConstantTexture(col(0.5, 3.0)))
+
+    def prim():
+        m = material()
+        if rs.rand() < 0.5:
+            a0, b0 = rs.uniform(-60, 30, 2)
+            return b.AARect(int(rs.randint(0, 3)), float(a0), float(a0 + rs.uniform(10, 60)), float(b0), float(b0 + rs.uniform(10, 60)), float(rs.uniform(-50, 50)), m)
+        mn = rs.uniform(-40, 20, 3)
+        return b.Cube(tuple(mn), tuple(mn + rs.uniform(8, 35, 3)), m)
+
+    def off(s=30.0):
+        return tuple(float(x) for x in rs.uniform(-s, s, 3))
+
+    def ang():
+        return float(rs.uniform(-80, 80))
+
+    def wrap(h):
+        k = rs.randint(0, 10)
+        if k == 0: return h
+        if k <= 3: return b.Translate(b.Rotate(1, h, ang()), off())                      # the instance idiom (main.rs:300-309)
+        if k == 4: return b.Translate(b.Rotate(int(rs.choice([0, 2])), h, ang()), off())  # same shape, another axis
+        if k == 5: return b.Rotate(1, b.Translate(h, off()), ang())                      # the two the other way round
+        if k == 6: return b.Translate(h, off())
+        if k == 7: return b.Rotate(int(rs.randint(0, 3)), h, ang())
+        if k == 8: return b.FlipNormal(b.Translate(b.Rotate(1, h, ang()), off()))         # three wrappers
+        return b.Translate(b.Rotate(1, b.Translate(b.Rotate(1, h, ang()), off()), ang()), off())   # the idiom twice
+
+    world = b.HittableList()
+    glow = b.DiffuseLight(b.ConstantTexture(col(4.0, 12.0)))
+    l1 = b.FlipNormal(b.AARect(Plane.XZ, -30.0, 30.0, -30.0, 30.0, 70.0, glow))
+    l2 = b.AARect(Plane.XY, -20.0, 20.0, 0.0, 40.0, 65.0, glow)
+    world.push(l1)
+    world.push(l2)
+    world.push(b.AARect(Plane.XZ, -200.0, 200.0, -200.0, 200.0, -55.0, b.Lambertian(b.ConstantTexture(col()))))
+    for _ in range(rs.randint(3, 10)):
+        world.push(wrap(prim()))
+    b.set_scene(world, [l1, l2][:int(rs.randint(0, 3))])
+    cam = Camera((float(rs.uniform(-30, 30)), float(rs.uniform(0, 50)), -170.0), (0.0, 5.0, 0.0), (0.0, 1.0, 0.0), 45.0, 1.0,
+                 float(rs.choice([0.0, 1.0])), 170.0, 0.0, 1.0)
+    return b, cam, col(0.0, 0.5)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_list_scene_parity(pbe, obe, seed):
+    from oracle import orc
+    ob, ocam, obg = _rand_list_scene(obe, seed)
+    pb, pcam, pbg = _rand_list_scene(pbe, seed)
+    W, H, spp, depth = 40, 40, 8, 12
+    ref, rs_, cnt = orc.render(ob, ocam, obg, W, H, spp, depth, seed=31 + seed, want_samples=True, want_counters=True)
+    got, gs = R.render(pb, pcam, pbg, W, H, spp, depth, seed=31 + seed, want_samples=True)
+    info = R.last_launch_info(pb)
+    assert info["threads"] == 256 and info["bvh_nodes"] == 0, "not the lean list-scene kernel"
+    assert np.array_equal(np.isnan(gs), np.isnan(rs_)), "NaN pattern differs"
+    assert np.array_equal(np.isinf(gs), np.isinf(rs_))
+    fin = np.isfinite(rs_)
+    d = np.abs(np.where(fin, gs, 0.0) - np.where(fin, rs_, 0.0))
+    bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, rs_, 0.0)))).any(axis=-1)
+    assert bad.sum() <= 2, f"seed {seed}: {int(bad.sum())} of {W * H * spp} samples diverged; first at {np.argwhere(bad)[:3].tolist()}"
+    assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
