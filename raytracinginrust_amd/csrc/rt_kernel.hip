@@ -65,11 +65,25 @@
 #ifndef RT_LEAN_STRAIGHT
 #define RT_LEAN_STRAIGHT 1
 #endif
+// Launch parameters that only the camera / work-queue / flush code reads are fetched from the kernel-argument segment where they are
+// used instead of living in scalar registers through the bounce loop (cold_params below).  *Measured* (round 4, A/B in one process,
+// samples bit-identical): spilled scalar registers 86 -> 12 (lean), 106 -> 12 (final scene's kernel), 143 -> 34 (mesh); VGPRs 121 -> 104
+// (lean), scratch 132 -> 64 B (final scene), 132 -> 56 (random spheres), 68 -> 24 (mesh); Cornell box +2.2 %, final scene +5.6 %,
+// teapot room +4.7 %, random spheres +2.5 % (profiles/r04_cold_params_ab.log).  0 = every parameter by value (A/B).
+#ifndef RT_COLD_PARAMS
+#define RT_COLD_PARAMS 1
+#endif
+// Lock-step loop: the path's pixel is the accumulator's (one register), the live-lane and flush counters are wave-uniform (scalar
+// registers).  With it and RT_COLD_PARAMS the lean kernel fits 96 VGPRs with 2 spilled (27 without) = 5 waves per SIMD: *measured*
+// Cornell box 27.8 ms (4 waves) -> 26.8 (5 waves) -> 26.2 (5 waves, slim) per 800x800x256; neutral in the BVH kernels.
+#ifndef RT_SLIM_STATE
+#define RT_SLIM_STATE 1
+#endif
 #ifndef RT_MERGE_METAL_DRAWS
 #define RT_MERGE_METAL_DRAWS 1
 #endif
 #ifndef RT_WAVES_LEAN
-#define RT_WAVES_LEAN 4
+#define RT_WAVES_LEAN 5      // (4 until round 4: see RT_SLIM_STATE)
 #endif
 #ifndef RT_WAVES_BVH
 #define RT_WAVES_BVH 4
@@ -145,6 +159,21 @@ template <typename T> DEV V3<T> ld3(const T* p) { return mk<T>(p[0], p[1], p[2])
 #define CAS __attribute__((address_space(4)))
 template <typename F> DEV F cl(const F* p) { return *(const CAS F*)p; }
 template <typename T> DEV V3<T> cl3(const T* p) { return mk<T>(cl(p), cl(p + 1), cl(p + 2)); }
+// Launch parameters that only the camera / work-queue code reads (camera, frame size, tiling, chunking, seed: ~60 scalar registers):
+// read from the kernel-argument segment where they are used, through a laundered pointer, instead of living in — and being spilled
+// from — scalar registers through the whole bounce loop.  (The kernel's only argument is the KParams block, at offset 0.)
+#if RT_COLD_PARAMS
+#define COLD_K const KParams<T>* K = cold_params<T>()
+#define PK(f) cl(&K->f)
+template <typename T> DEV const KParams<T>* cold_params() {
+    const KParams<T>* k = (const KParams<T>*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(k));
+    return k;
+}
+#else
+#define COLD_K const KParams<T>* K = &P
+#define PK(f) (K->f)
+#endif
 // Whole-record fetch of a 16-byte-aligned POD record as 16-byte (then 8 / 4-byte) pieces through the constant address space.
 template <typename R> DEV R ld_record(const R* p) {
     static_assert(alignof(R) >= 16 && sizeof(R) % 4 == 0, "record must be 16-byte aligned");
@@ -1081,10 +1110,12 @@ DEV double wave_sum(double x) {                      // fixed butterfly: determi
 // Lanes with `need` set hold a partial per-pixel sum (acc) for local pixel acc_px.  All partials of one pixel are
 // combined by a masked butterfly and added to out[] by one lane with one f64 atomic per channel (a handful per pixel
 // per frame: this is the kernel's only global write traffic).
-template <typename A>
-DEV void flush_acc(bool need, uint32_t acc_px, const A& acc, double* out, uint32_t lane, uint32_t& n_flush) {
+template <typename T, typename A>
+DEV void flush_acc(const KParams<T>& P, bool need, uint32_t acc_px, const A& acc, uint32_t lane, uint32_t& n_flush) {
     unsigned long long m = __ballot(need);
     while (m) {
+        COLD_K;
+        double* const out = PK(out);
         uint32_t leader = (uint32_t)__builtin_ctzll(m);
         uint32_t px = (uint32_t)__builtin_amdgcn_readlane((int)acc_px, (int)leader);
         bool mine = need && acc_px == px;
@@ -1094,8 +1125,13 @@ DEV void flush_acc(bool need, uint32_t acc_px, const A& acc, double* out, uint32
         if (lane == leader) {
             double* o = out + (size_t)px * 3u;        // hardware f64 atomics: a pixel's samples may be split over several waves
             unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2);
+#if !RT_SLIM_STATE
             n_flush++;
+#endif
         }
+#if RT_SLIM_STATE
+        n_flush++;                                    // wave-uniform (a scalar register)
+#endif
         need = need && !mine;
         m = __ballot(need);
     }
@@ -1128,25 +1164,27 @@ struct WaveWork {
     uint32_t q_head, q_count;
     bool queue_done;
 };
-template <typename T> DEV void locate(const KParams<T>& P, WaveWork& w) {   // local pixel -> global output-order pixel (tile t = rank + q * world)
-    uint32_t q = w.cur_px / P.tile_px, kk = w.cur_px - q * P.tile_px;
-    w.cur_gp = (P.rank + q * P.world) * P.tile_px + kk;
-    uint32_t row = w.cur_gp / P.W;
-    w.cur_i = w.cur_gp - row * P.W;
-    w.cur_j = P.H - 1u - row;           // row 0 is j = H-1, main.rs:772
+template <typename T> DEV void locate(const KParams<T>& P, WaveWork& w) {
+    COLD_K;   // local pixel -> global output-order pixel (tile t = rank + q * world)
+    uint32_t q = w.cur_px / PK(tile_px), kk = w.cur_px - q * PK(tile_px);
+    w.cur_gp = (PK(rank) + q * PK(world)) * PK(tile_px) + kk;
+    uint32_t row = w.cur_gp / PK(W);
+    w.cur_i = w.cur_gp - row * PK(W);
+    w.cur_j = PK(H) - 1u - row;           // row 0 is j = H-1, main.rs:772
 }
 // Point the cursor at work chunk c (KParams: whole pixels first, then pieces of chunk_spp samples of one pixel).
 template <typename T> DEV void take_chunk(const KParams<T>& P, WaveWork& w, uint32_t c) {
-    const uint32_t n_local_px = P.n_local_tiles * P.tile_px;
-    if (c < P.n_coarse_px) {                      // a whole pixel
-        w.cur_px = c; w.end_px = c + 1u; w.s_lo = 0u; w.s_hi = P.spp;
+    COLD_K;
+    const uint32_t n_local_px = PK(n_local_tiles) * PK(tile_px);
+    if (c < PK(n_coarse_px)) {                      // a whole pixel
+        w.cur_px = c; w.end_px = c + 1u; w.s_lo = 0u; w.s_hi = PK(spp);
     } else {
-        const uint32_t c2 = c - P.n_coarse_px;
-        const uint32_t cp = c2 / P.chunks_per_px, sub = c2 - cp * P.chunks_per_px;
-        w.cur_px = P.n_coarse_px + cp * P.chunk_px;
-        w.end_px = w.cur_px + P.chunk_px; if (w.end_px > n_local_px) w.end_px = n_local_px;
-        w.s_lo = sub * P.chunk_spp;
-        w.s_hi = w.s_lo + P.chunk_spp; if (w.s_hi > P.spp) w.s_hi = P.spp;
+        const uint32_t c2 = c - PK(n_coarse_px);
+        const uint32_t cp = c2 / PK(chunks_per_px), sub = c2 - cp * PK(chunks_per_px);
+        w.cur_px = PK(n_coarse_px) + cp * PK(chunk_px);
+        w.end_px = w.cur_px + PK(chunk_px); if (w.end_px > n_local_px) w.end_px = n_local_px;
+        w.s_lo = sub * PK(chunk_spp);
+        w.s_hi = w.s_lo + PK(chunk_spp); if (w.s_hi > PK(spp)) w.s_hi = PK(spp);
     }
     w.cur_s = w.s_lo;
     locate(P, w);
@@ -1155,17 +1193,18 @@ template <typename T> DEV void take_chunk(const KParams<T>& P, WaveWork& w, uint
 // global work queue is exhausted and nothing was generated.
 template <typename T>
 DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real, uint32_t* q_u32) {
-    const uint32_t QN = P.queue_entries;          // 16, 32 or 64 (wave-uniform: the host gives BVH kernels what LDS the node cache leaves)
-    const uint32_t n_px = P.W * P.H;
+    COLD_K;
+    const uint32_t QN = PK(queue_entries);          // 16, 32 or 64 (wave-uniform: the host gives BVH kernels what LDS the node cache leaves)
+    const uint32_t n_px = PK(W) * PK(H);
     bool have = false;
     uint32_t g_px = 0, g_s = 0, g_gp = 0, g_i = 0, g_j = 0;
     uint32_t n_gen = 0;
     while (n_gen < QN) {
         if (w.cur_px == w.end_px) {
             uint32_t c = 0;
-            if (lane == 0) c = atomicAdd(P.queue, 1u);
+            if (lane == 0) c = atomicAdd(PK(queue), 1u);
             c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-            if (c >= P.n_chunks) { w.queue_done = true; break; }
+            if (c >= PK(n_chunks)) { w.queue_done = true; break; }
             take_chunk(P, w, c);
         }
         if (w.cur_gp >= n_px || w.s_lo >= w.s_hi) { w.cur_px++; w.cur_s = w.s_lo; if (w.cur_px != w.end_px) locate(P, w); continue; }   // padding pixel / empty range
@@ -1179,11 +1218,11 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
     }
     if (n_gen == 0) return false;
     if (have) {
-        Rng g = rng_for_path(P.seed, g_gp, g_s);
+        Rng g = rng_for_path(PK(seed), g_gp, g_s);
         T random_u = rng_u01(g, T(0));
         T random_v = rng_u01(g, T(0));
-        T u = (T(g_i) + random_u) / T(P.W - 1u);
-        T v = (T(g_j) + random_v) / T(P.H - 1u);
+        T u = (T(g_i) + random_u) / T(PK(W) - 1u);
+        T v = (T(g_j) + random_v) / T(PK(H) - 1u);
         // Camera::get_ray, camera.rs:51-59 (random_in_unit_disk, vec.rs:96-105)
         T da, db;
         for (;;) {
@@ -1192,11 +1231,11 @@ DEV bool refill_queue(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_real
             V3<T> pd = mk<T>(da, db, T(0));
             if (dot(pd, pd) < T(1.0)) break;       // `p.length() < 1.0` (vec.rs:101): sqrt(x) < 1 <=> x < 1
         }
-        V3<T> rd = P.cam.lens_radius * mk<T>(da, db, T(0));
-        V3<T> offset = ld3(P.cam.cu) * rd.x + ld3(P.cam.cv) * rd.y;
-        T time = P.cam.time0 + rng_u01(g, T(0)) * (P.cam.time1 - P.cam.time0);
-        V3<T> go = ld3(P.cam.origin) + offset;
-        V3<T> gd = ld3(P.cam.lower_left_corner) + u * ld3(P.cam.horizontal) + v * ld3(P.cam.vertical) - (ld3(P.cam.origin) + offset);
+        V3<T> rd = PK(cam.lens_radius) * mk<T>(da, db, T(0));
+        V3<T> offset = cl3(K->cam.cu) * rd.x + cl3(K->cam.cv) * rd.y;
+        T time = PK(cam.time0) + rng_u01(g, T(0)) * (PK(cam.time1) - PK(cam.time0));
+        V3<T> go = cl3(K->cam.origin) + offset;
+        V3<T> gd = cl3(K->cam.lower_left_corner) + u * cl3(K->cam.horizontal) + v * cl3(K->cam.vertical) - (cl3(K->cam.origin) + offset);
         q_real[0u * QN + lane] = go.x; q_real[1u * QN + lane] = go.y; q_real[2u * QN + lane] = go.z;
         q_real[3u * QN + lane] = gd.x; q_real[4u * QN + lane] = gd.y; q_real[5u * QN + lane] = gd.z;
         q_real[6u * QN + lane] = time;
@@ -1447,7 +1486,11 @@ DEV unsigned long long* stats_row(unsigned long long* stats) {     // one of the
 DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfinite, unsigned long long n_iters, unsigned long long n_active, uint32_t n_flush) {
     if (!stats) return;
     if (n_nonfinite) atomicAdd(&stats[0], (unsigned long long)n_nonfinite);
+#if RT_SLIM_STATE
+    if (lane == 0 && n_flush) atomicAdd(&stats[11], (unsigned long long)n_flush);
+#else
     if (n_flush) atomicAdd(&stats[11], (unsigned long long)n_flush);
+#endif
     if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], n_active); }      // (both wave-uniform: kept in scalar registers)
 }
 
@@ -1462,7 +1505,12 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     bool alive = false;
     RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
     V3<T> beta = mk<T>(T(0), T(0), T(0));
+#if RT_SLIM_STATE
+    uint32_t depth_left = 0, path_s = 0;                 // (the path's pixel is the accumulator's: acc_px)
+#define path_px acc_px
+#else
     uint32_t depth_left = 0, path_px = 0, path_s = 0;
+#endif
     Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
@@ -1481,18 +1529,24 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_ADD(0);
 
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
+        flush_acc(P, got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, lane, n_flush);
 
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
+#if !RT_SLIM_STATE
             path_px = new_px;
+#endif
             beta = mk<T>(T(1.0), T(1.0), T(1.0));
             depth_left = P.max_depth;
             alive = true;
         }
 
         n_iters++;
+#if RT_SLIM_STATE
+        n_active += (unsigned long long)__popcll(__ballot(alive));
+#else
         if (alive) n_active++;
+#endif
         DIAG_ADD(1);
 
         // ---- one level of ray_color (main.rs:41-120) for every live lane
@@ -1532,17 +1586,20 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         }
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
-    unsigned long long* const st = stats_row(P.stats);
-    unsigned long long live = n_active;                 // (per-lane here: a scalar count made this kernel's register allocation worse)
+    flush_acc(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
+    unsigned long long* st; { COLD_K; st = stats_row(PK(stats)); }
+    unsigned long long live = n_active;
+#if !RT_SLIM_STATE
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
+#endif
     write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
 #ifdef RT_DIAG
     if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
 #endif
 }
 
+#undef path_px
 // ------------------------------------------------------------------ BVH scenes: resumable closest-hit search, persistent traversal
 // With a BVH in the scene the cost of `world.hit` differs wildly between lanes (a ray that misses the root box is done
 // after one node, its neighbour walks a hundred), and in lock-step every lane waits for the slowest one: *measured* VALU
@@ -1706,7 +1763,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
         DIAG_ADD(2);
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, P.out, lane, n_flush);
+        flush_acc(P, got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, lane, n_flush);
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
             path_px = new_px;
@@ -1736,8 +1793,8 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         DIAG_ADD(4);
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(acc_px != NONE_PX, acc_px, acc, P.out, lane, n_flush);
-    unsigned long long* const st = stats_row(P.stats);
+    flush_acc(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
+    unsigned long long* st; { COLD_K; st = stats_row(PK(stats)); }
     write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
     if (st) {
         if (lane == 0) { atomicAdd(&st[9], n_steps + n_leaf_steps); atomicAdd(&st[10], n_step_lanes + n_leaf_lanes); atomicAdd(&st[12], n_leaf_steps); atomicAdd(&st[13], n_leaf_lanes); }
@@ -1797,7 +1854,7 @@ static int occupancy_one(size_t shmem) {
 template <uint32_t FEATS> static LaunchShape shape_one() { LaunchShape g; g.threads = Shape<FEATS>::THREADS; g.queue_entries = Shape<FEATS>::QN_MIN; g.one_per_cu = Shape<FEATS>::ONE_PER_CU; return g; }
 
 // Instantiations per arithmetic type, leanest first: rects + instances + Lambertian/Metal/DiffuseLight (everything the
-// Cornell box needs; 4 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
+// Cornell box needs; 5 waves/SIMD), the same plus BVH + triangles (mesh scenes such as the teapot room; 3 waves/SIMD),
 // everything but the principled material (3 waves/SIMD with some spilling: measured 6 % faster on the final scene than
 // 2 waves/SIMD without), and everything (2 waves/SIMD); the BVH ones also with near-first traversal.
 static const uint32_t FEATS_LEAN = 0u;
