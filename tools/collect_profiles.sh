@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 TAG=$1; shift
 for W in "$@"; do
   tail -1 gpurun_out/prof_${TAG}_$W/bench.json > profiles/${TAG}_bench_$W.json
-  cp gpurun_out/prof_${TAG}_$W/trace/*/*_kernel_stats.csv profiles/${TAG}_bench_${W}_kernel_stats.csv
+  cp "$(ls -t gpurun_out/prof_${TAG}_$W/trace/*/*_kernel_stats.csv | head -n 1)" profiles/${TAG}_bench_${W}_kernel_stats.csv   # (the newest: gpurun_out keeps earlier runs)
   cp gpurun_out/pmc_${TAG}_$W/summary.csv profiles/${TAG}_bench_${W}_pmc_summary.csv
 done
 ls -la profiles/${TAG}_*
