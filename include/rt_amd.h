@@ -51,11 +51,6 @@ enum {
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
-    RT_JOINT_BVH = 256,    /* scheduling only, same samples (lock-step BVH kernels, reference order; scenes with exactly two bare BVH objects): both trees
-                              are walked in one loop at the first one's place in the list — a lane whose ray enters only the second starts it at
-                              once — and the second tree's result joins the list search at its own place (rt_kernel.hip: joint_walk).  Chosen
-                              automatically for such scenes (the final scene; measured +5 %); the flag only matters together with ...     */
-    RT_NO_JOINT_BVH = 512, /* ... this one, which forces the two plain walks                                                       */
     RT_SPECULATE_BVH = 1024, /* scheduling only, same samples (lock-step BVH kernel): a lane that has reached a leaf walks on while it waits for the
                               leaf step (rt_kernel.hip: bvh_hit_spec).  Chosen automatically for scenes whose world is one BVH (every ray
                               enters it); this flag forces it on ...                                                          */

@@ -506,24 +506,13 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
         if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size() && f.bvh.size() >= 640u * n_bvh_objects * n_bvh_objects) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
-    // Two trees, one walk (scheduling only, rt_kernel.hip: joint_walk): scenes with exactly two bare BVH objects, reference-order lock-step
-    // kernels — the final scene (ground boxes + sphere cluster), rooms with two small meshes.  *Measured* (round 4, once the launch
-    // parameters had left the scalar registers: before that the loop's extra state spilled and it lost 2-14 %): final scene 15.24 ->
-    // 14.49 ms per 400x400x64 (+5 %), two-mesh rooms +6 ... +7.5 %, samples bit-identical (profiles/r04_joint_walk_adopted.log).
-    {
-        size_t n_bare = 0;
-        for (const DObject& ob : f.objects) n_bare += (ob.geom_kind == G_BVH && ob.medium < 0) ? 1u : 0u;
-        const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && n_bare == 2 && !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
-        if (can && !(flags & RT_NO_JOINT_BVH)) out |= RT_JOINT_BVH;
-        if (!can || (flags & RT_NO_JOINT_BVH)) out &= ~(uint32_t)RT_JOINT_BVH;
-    }
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
     // enters it, which is where walking on past an untested leaf pays (*measured* random spheres +2.6 %; scenes whose trees few lanes
     // enter lose 3 %)
     {
         const bool one_bvh = f.objects.size() == 1 && f.objects[0].geom_kind == G_BVH && f.objects[0].medium < 0;
         const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u &&
-                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH | RT_JOINT_BVH));
+                         !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
         if (can && one_bvh && !(flags & RT_NO_SPECULATE_BVH)) out |= RT_SPECULATE_BVH;
         if (!can || (flags & RT_NO_SPECULATE_BVH)) out &= ~(uint32_t)RT_SPECULATE_BVH;
     }
@@ -562,7 +551,6 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.n_bvh = (uint32_t)f.bvh.size();
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
-    { P.joint0 = P.joint1 = 0xFFFFFFFFu; for (uint32_t i = 0; i < (uint32_t)f.objects.size(); i++) if (f.objects[i].geom_kind == G_BVH && f.objects[i].medium < 0) { if (P.joint0 == 0xFFFFFFFFu) P.joint0 = i; else if (P.joint1 == 0xFFFFFFFFu) P.joint1 = i; } }
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
     {   // the f32 tables are rounded copies: the tame bound is checked at the precision that is uploaded
         const double big = sizeof(T) == 8 ? 1e300 : 1e30;

@@ -43,7 +43,6 @@ enum Feat : uint32_t {
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
-    F_JOINT = 1u << 9,      // not a scene feature: lock-step loop that walks the scene's two bare BVH objects in one loop (RT_JOINT_BVH)
     F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
 
@@ -117,7 +116,6 @@ template <typename T> struct KParams {
     uint32_t trav_hi, trav_lo, trav_leaf;      // trav_leaf: a leaf step runs once trav_leaf/64 of the walking lanes hold a pending leaf
     // debugging aid (-DRT_TRACE_PATH builds, rt_debug_trace_path): the path (trace_px, trace_s) writes 16 doubles per level to trace_out
     double* trace_out; uint32_t trace_px, trace_s;
-    uint32_t joint0, joint1;       // F_JOINT kernels: the list positions of the scene's two bare BVH objects (joint0 < joint1)
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
 };
 

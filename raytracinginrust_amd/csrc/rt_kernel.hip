@@ -707,139 +707,6 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
     return any;
 }
 
-// ------------------------------------------------------------------ two trees, one walk (F_JOINT instantiations, RT_JOINT_BVH)
-// A scene with TWO bare BVH objects in its list (the final scene: the ground boxes' tree first, the sphere cluster's tree last, eight
-// objects between them) walks them one after the other, each entered by a minority of the wave's lanes (*measured*: 27 and 12 of 59) that
-// seldom coincide.  Here both are walked in ONE loop at the first tree's place in the list: a lane whose ray enters only the second tree
-// starts it at once, a lane in both walks the first and then the second, and the wave's loop is as long as its longest lane — not the
-// sum of the two trees' longest.  Node ids are global, so the step loop is the plain one (bvh_hit_ww); a lane simply carries the ray of
-// the tree it is in.
-// The first tree's walk is the reference's (its t_max is the true closest hit at its place in the list).  The second tree is walked
-// EARLY: the objects between the trees have not been searched yet, so its t_max is only a bound B >= the closest hit c the list search
-// will hold at the second tree's place (closest hits only shrink).  BVH::hit(c) follows from the walk with B exactly:
-//   * a box or a leaf's primitives rejected under B are rejected under c <= B;
-//   * by containment (a child's slab interval lies inside its parent's, in floating point) the recursion tests leaf X under c iff X's
-//     own box passes, c > t_in(X), and then accepts X's winner t* (minimum, later primitive on ties — the same winner under any t_max
-//     >= c) iff t* <= c;
-//   * the leaves accepted under B form a chain k1, k2, ... with shrinking t*; the walk keeps the last one, which decides for every c as
-//     long as each step of the chain had t_in(k2) < t*(k1) and t*(k2) <= t*(k1) — always, unless a primitive hit lies in front of its own
-//     box by rounding and the next leaf falls into that one-ulp gap: then `dirty` is raised and the lane walks the second tree again
-//     at its place in the list, with the true c (counted; not observed).
-// So at the second tree's place the list search takes  (c > t_in && t* <= c) ? (t*, primitive) : nothing.  No random number is drawn in
-// a BVH walk (medium.rs:28 draws in ConstantMedium::hit only), so the path's RNG stream is untouched.  Tame rays only; otherwise the two
-// plain walks.
-struct JointKeep { bool dirty; uint32_t prim; };      // (with k_tin, k_t: what the second tree's early walk leaves for its place in the list)
-template <typename T, uint32_t FEATS>
-DEV void joint_walk(const KParams<T>& P, bool pass0, uint32_t root0, const RayT<T>& r0, bool pass1, uint32_t root1, const RayT<T>& ray_world, const DObject& ob1, T t_min,
-                    T& closest, uint32_t& prim0, bool& any0, T& k_tin, T& k_t, JointKeep& keep) {
-    const uint32_t DONE = 0xFFFFFFFFu;
-    uint32_t stage = pass0 ? 0u : (pass1 ? 1u : 2u);
-    RayT<T> w = r0;
-    if (!pass0) { w = ray_world; for (uint32_t k = 0; k < ob1.n_ops; k++) op_fwd(ld_op(P.ops + ob1.first_op + k), w); }
-    V3<T> inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
-    uint32_t node = stage == 0u ? root0 : (stage == 1u ? root1 : DONE);
-    T bound = closest;                                  // stage 0: the recursion's closest hit; stage 1: >= the closest hit at the second tree's place
-    uint32_t leaf_a = 0, leaf_b = 0;
-    T leaf_tin = T(0);                                  // t_in of the pending leaf's box (second tree)
-    bool have_leaf = false;
-    keep.dirty = false; keep.prim = DONE; k_tin = T(0); k_t = T(0);
-    any0 = false;
-    for (;;) {
-        for (;;) {
-            const bool want_box = node != DONE && !have_leaf;
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
-            if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
-            auto box_step = [&]() {
-                const DBvhNode<T> nd = fetch_node(P, node);
-                // box_inside_tame, with its t_in kept: a leaf of the second tree needs it when its primitives have been tested
-                const T ax = (nd.mn[0] - w.o.x) * inv.x, bx = (nd.mx[0] - w.o.x) * inv.x;
-                const T ay = (nd.mn[1] - w.o.y) * inv.y, by = (nd.mx[1] - w.o.y) * inv.y;
-                const T az = (nd.mn[2] - w.o.z) * inv.z, bz = (nd.mx[2] - w.o.z) * inv.z;
-                const T t_in = max_nn(max_nn(max_nn(min_nn(ax, bx), t_min), min_nn(ay, by)), min_nn(az, bz));
-                const T t_o = min_nn(min_nn(min_nn(max_nn(ax, bx), bound), max_nn(ay, by)), max_nn(az, bz));
-                const bool inside = t_o > t_in;
-                if (inside && (nd.a & BVH_LEAF)) { have_leaf = true; leaf_a = nd.a; leaf_b = nd.b; leaf_tin = t_in; }
-                node = (inside && !(nd.a & BVH_LEAF)) ? nd.c : nd.skip;
-            };
-            if (want_box) box_step();
-#pragma unroll
-            for (int k = 1; k < RT_BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
-        }
-        if (have_leaf) {
-            T t; uint32_t prim;
-            if (range_hit<T, FEATS>(P, (leaf_a >> 28) & 7u, leaf_a & 0x0FFFFFFFu, leaf_b, w, t_min, bound, t, prim)) {
-                if (stage == 0u) { bound = t; prim0 = prim; any0 = true; }              // hit.rs:62-69
-                else {
-                    if (keep.prim != DONE && !(leaf_tin < k_t && t <= k_t)) keep.dirty = true;
-                    bound = t > leaf_tin ? t : leaf_tin;
-                    k_tin = leaf_tin; k_t = t; keep.prim = prim;
-                }
-            }
-            have_leaf = false;
-        }
-        // ---- a lane that has finished the first tree: its result is the list search's (exact); on to the second tree if its ray enters it
-        const bool sw = stage == 0u && node == DONE && !have_leaf;
-        if (__ballot(sw) != 0ull) {
-            if (sw) {
-                closest = bound;                                                       // (unchanged when nothing was hit)
-                if (pass1) {
-                    stage = 1u; node = root1;
-                    w = ray_world; for (uint32_t k = 0; k < ob1.n_ops; k++) op_fwd(ld_op(P.ops + ob1.first_op + k), w);      // (the second tree's object-space ray, from the world-space one)
-                    inv = mk<T>(T(1.0) / w.d.x, T(1.0) / w.d.y, T(1.0) / w.d.z);
-                } else stage = 2u;
-            }
-        }
-        if (__ballot(node != DONE || have_leaf) == 0ull) break;
-    }
-}
-
-template <typename T, uint32_t FEATS>
-DEV bool world_hit_joint(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id, uint32_t* stack) {
-    T closest = Lim<T>::inf();
-    bool any = false;
-    T k_tin = T(0), k_t = T(0); JointKeep keep; keep.dirty = false; keep.prim = 0xFFFFFFFFu;
-    bool joint_done = false;                            // (wave-uniform) the second tree was walked early
-    for (uint32_t oi = 0; oi < P.n_objects; oi++) {          // wave-uniform: scalar loads
-        const DObject ob = ld_obj(P.objects + oi);
-        if (oi == P.joint0) {
-            const DObject ob1 = ld_obj(P.objects + P.joint1);
-            RayT<T> r0 = ray, r1 = ray;
-            for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r0);
-            for (uint32_t k = 0; k < ob1.n_ops; k++) op_fwd(ld_op(P.ops + ob1.first_op + k), r1);
-            const V3<T> i0 = mk<T>(T(1.0) / r0.d.x, T(1.0) / r0.d.y, T(1.0) / r0.d.z), i1 = mk<T>(T(1.0) / r1.d.x, T(1.0) / r1.d.y, T(1.0) / r1.d.z);
-            if (P.bvh_tame != 0u && __ballot(!(ray_is_tame(r0.o, i0) && ray_is_tame(r1.o, i1))) == 0ull) {
-                // AABB::hit of the roots (bvh.rs:78); the second one with the closest hit as it is now: a failure is final (it only shrinks)
-                const bool pass0 = box_inside_tame(fetch_node(P, ob.geom_first), r0.o, i0, t_min, closest);
-                const bool pass1 = box_inside_tame(fetch_node(P, ob1.geom_first), r1.o, i1, t_min, closest);
-                joint_done = true;
-                if (__ballot(pass0 || pass1) != 0ull) {
-                    uint32_t prim0 = 0; bool any0 = false;
-                    joint_walk<T, FEATS>(P, pass0, ob.geom_first, r0, pass1, ob1.geom_first, ray, ob1, t_min, closest, prim0, any0, k_tin, k_t, keep);
-                    if (any0) { id.obj = oi; id.prim = prim0; any = true; }
-                }
-                continue;
-            }
-        }
-        if (oi == P.joint1 && joint_done) {
-            // the second tree's place in the list: BVH::hit(t_max = closest) from what its early walk kept
-            if (__ballot(keep.dirty) != 0ull) {
-                if (keep.dirty) {
-                    RayT<T> r1 = ray;
-                    for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r1);
-                    T t; uint32_t prim;
-                    if (bvh_hit_ww<T, FEATS>(P, ob.geom_first, r1, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
-                    if (P.stats) atomicAdd(&P.stats[13], 1ull);
-                }
-            }
-            if (!keep.dirty && keep.prim != 0xFFFFFFFFu && closest > k_tin && k_t <= closest) { closest = k_t; id.obj = oi; id.prim = keep.prim; any = true; }
-            continue;
-        }
-        object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
-    }
-    t_hit = closest;
-    return any;
-}
-
 // get_sphere_uv, sphere.rs:11-25
 template <typename T> DEV void sphere_uv(V3<T> p, T& u, T& v) {
     T phi = m_atan2(-p.z, p.x) + PI_T;
@@ -1690,8 +1557,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
                 done = true;                            // main.rs:42-45
             } else {
                 T t_hit; HitId id; id.obj = 0; id.prim = 0;
-                const bool any_hit = (FEATS & F_JOINT) ? world_hit_joint<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack)
-                                                       : world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
+                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
                 DIAG_ADD(2);
                 if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
@@ -2014,15 +1880,12 @@ template __global__ void pathtrace_kernel<double, RT_KRES_ONLY>(const KParams<do
 template <typename T, typename F, typename L> static auto dispatch(uint32_t scene_feats, uint32_t flags, L&& lean, F&& f) {
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
-    const bool jn = (flags & 256u) && (scene_feats & F_BVH) && !nf && !ps;      // RT_JOINT_BVH (reference-order lock-step family)
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
     if ((scene_feats & ~FEATS_MESH) == 0u) {
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
-        if (jn) return f(std::integral_constant<uint32_t, FEATS_MESH | F_JOINT>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());
     }
     if ((scene_feats & ~FEATS_NO_PBR) == 0u) {
-        if (jn) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_JOINT>());
         if ((flags & 1024u) && !nf && !ps) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_SPEC>());      // RT_SPECULATE_BVH
         if (ps && !nf) return f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_NO_PBR | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_NO_PBR>());

@@ -15,7 +15,6 @@ from .api import CameraParams, SceneBuilder
 RT_F64, RT_F32, RT_STOP_ON_ZERO, RT_ISOTROPIC_SCATTER, RT_NEAR_FIRST_BVH = 0, 1, 2, 4, 8
 RT_PERSISTENT_BVH, RT_LOCKSTEP_BVH = 16, 32
 RT_MULTI_COLLECTIVE = 64
-RT_JOINT_BVH, RT_NO_JOINT_BVH = 256, 512
 RT_SPECULATE_BVH, RT_NO_SPECULATE_BVH = 1024, 2048
 FLATTEN_COUNT_NAMES = ("objects", "ops", "rects", "spheres", "moving_spheres", "triangles", "bvh_nodes",
                        "materials", "textures", "lights", "media", "perlins")

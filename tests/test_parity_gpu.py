@@ -769,26 +769,6 @@ def test_speculative_box_steps_are_scheduling_only(name, pbe, obe, orc_mod, eart
     assert n_div <= MAX_DIVERGED
 
 
-@pytest.mark.parametrize("name", ["final", "mesh0", "mesh3", "mesh11"])
-def test_joint_walk_of_two_trees_is_scheduling_only(name, pbe, obe, orc_mod, earth):
-    """RT_JOINT_BVH (the default for scenes with exactly two bare BVH objects: the final scene, two-mesh rooms): both trees are walked in
-    one loop at the first one's place in the list, the second tree's early result joins the list search at its own place (rt_kernel.hip:
-    joint_walk; exact by the kept-leaf rule `c > t_in && t* <= c`, with a fallback walk when a primitive hit lies in front of its own box
-    by rounding).  Every sample is bit-identical to the two plain walks and matches the oracle."""
-    mk = (lambda be: _mesh_room(be, int(name[4:]))) if name.startswith("mesh") else (lambda be: build_scene(name, be, earth))
-    b, cam, bg = mk(pbe)
-    W, H, spp, depth = 96, 54, 8, 30
-    _, plain = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_NO_JOINT_BVH | R.RT_NO_SPECULATE_BVH, want_samples=True)
-    _, joint = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH | R.RT_JOINT_BVH, want_samples=True)
-    assert np.array_equal(plain.view(np.uint64), joint.view(np.uint64))
-    _, auto = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
-    assert np.array_equal(plain.view(np.uint64), auto.view(np.uint64))
-    ob, ocam, obg = mk(obe)
-    _, ref = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
-    n_div, _, _ = _compare_samples(joint, ref)
-    assert n_div <= MAX_DIVERGED
-
-
 def test_rotation_by_an_angle_whose_sincos_differs_from_sin_and_cos(pbe, obe, orc_mod):
     """Found by the round-3 fuzz sweep (seed 38793: 35 diverged samples in one scene).  glibc's sincos() differs from its sin() / cos() in
     the last ulp for 0.13 % of arguments — one of them (pi/180) * -73.5789378649801 — and LLVM (hence rustc) turns `radians.sin()` /
