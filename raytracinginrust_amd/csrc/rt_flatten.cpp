@@ -406,6 +406,31 @@ void relayout_bvh_by_depth(HostFlat& f) {
     for (DObject& ob : f.objects) if (ob.geom_kind == G_BVH) ob.geom_first = new_id[ob.geom_first];
 }
 
+// The filtered walk's nodes (rt_kernel.hip: bvh_hit_filt): each f64 box rounded OUTWARD to f32, the same skip link, and the one word a
+// passing box step moves to — the left child, or for a leaf its own id with FNODE_LEAF set.
+void make_filter_nodes(HostFlat& f) {
+    const size_t n = f.bvh.size();
+    f.bvh_f.assign(n, DFNode{});
+    f.filter_m = 0.0f;
+    if (n == 0 || n >= FNODE_LEAF) return;
+    const float neg_inf = -std::numeric_limits<float>::infinity(), pos_inf = std::numeric_limits<float>::infinity();
+    auto down = [&](double x) { float v = (float)x; if ((double)v > x) v = std::nextafterf(v, neg_inf); return v; };
+    auto up = [&](double x) { float v = (float)x; if ((double)v < x) v = std::nextafterf(v, pos_inf); return v; };
+    float m = 1.0f; bool ok = true;
+    for (size_t i = 0; i < n; i++) {
+        const DBvhNode<double>& nd = f.bvh[i];
+        DFNode& o = f.bvh_f[i];
+        for (int k = 0; k < 3; k++) {
+            o.b[2 * k] = down(nd.mn[k]); o.b[2 * k + 1] = up(nd.mx[k]);
+            ok = ok && std::isfinite(o.b[2 * k]) && std::isfinite(o.b[2 * k + 1]) && nd.mn[k] <= nd.mx[k];
+            m = std::fmax(m, std::fmax(std::fabs(o.b[2 * k]), std::fabs(o.b[2 * k + 1])));
+        }
+        o.skip = nd.skip;
+        o.info = (nd.a & BVH_LEAF) ? ((uint32_t)i | FNODE_LEAF) : nd.c;
+    }
+    if (ok && m <= 0x1p40f) f.filter_m = m;
+}
+
 } // namespace
 
 bool flatten_scene(Scene& s) {
@@ -418,6 +443,7 @@ bool flatten_scene(Scene& s) {
     for (const DBvhNode<double>& nd : s.flat.bvh)
         for (int k = 0; k < 3; k++)
             if (!(std::fabs(nd.mn[k]) < 1e300 && std::fabs(nd.mx[k]) < 1e300 && nd.mn[k] <= nd.mx[k])) s.flat.bvh_tame = false;
+    make_filter_nodes(s.flat);
     s.flat_valid = true;
     return true;
 }

@@ -33,7 +33,7 @@ static int scene_err(rt_scene* sc, const std::string& m) { sc->s.error = m; g_er
 static void free_dev(void*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 template <typename T> static void free_device_scene(DeviceScene<T>& d) {
     free_dev(d.objects); free_dev(d.ops); free_dev(d.rects); free_dev(d.spheres); free_dev(d.mspheres); free_dev(d.tris);
-    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr);
+    free_dev(d.bvh); free_dev(d.materials); free_dev(d.textures); free_dev(d.media); free_dev(d.lights); free_dev(d.perlins); free_dev(d.image); free_dev(d.pbr); free_dev(d.bvh_f);
     d.valid = false;
 }
 
@@ -407,6 +407,7 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DMSphere<T>>(f.mspheres, d.mspheres)) return -1;
     if (upload_vec<DTri<T>>(f.tris, d.tris)) return -1;
     if (upload_vec<DBvhNode<T>>(f.bvh, d.bvh)) return -1;
+    if (sizeof(T) == 8u) { std::vector<DFNode> fn(f.bvh_f); fn.push_back(DFNode{}); if (upload_raw(fn, d.bvh_f)) return -1; }      // (one padding record, as upload_vec)
     if (upload_vec<DMaterial<T>>(f.materials, d.materials)) return -1;
     if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
     if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
@@ -521,13 +522,15 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
 
 // BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
 // queues and stacks; 0 for the list-scene kernels.
-template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop, uint32_t stack_depth) {
+template <typename T> size_t lds_node_bytes(uint32_t effective) { return filtered_walk(sizeof(T) == 8u, effective) ? sizeof(DFNode) : sizeof(DBvhNode<T>); }
+template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop, uint32_t stack_depth, uint32_t effective) {
     if (!g.one_per_cu || f.bvh.empty()) return 0u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor;
     if (lds_total < 65536u) lds_total = 65536u;
-    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, sizeof(DBvhNode<T>));
-    if (fixed + sizeof(DBvhNode<T>) > lds_total) return 0u;
-    size_t room = (lds_total - fixed) / sizeof(DBvhNode<T>);
+    const size_t nb = lds_node_bytes<T>(effective);
+    const size_t fixed = pathtrace_lds_bytes(g, stack_depth, 0u, nb);
+    if (fixed + nb > lds_total) return 0u;
+    size_t room = (lds_total - fixed) / nb;
     // RT_NODE_CACHE_MAX (tests, A/B runs): stage at most that many nodes (0 = every node comes from global memory); scheduling only
     if (const char* v = std::getenv("RT_NODE_CACHE_MAX")) { const long n = std::strtol(v, nullptr, 10); if (n >= 0 && (size_t)n < room) room = (size_t)n; }
     return (uint32_t)std::min(room, f.bvh.size());
@@ -549,6 +552,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
     P.n_bvh = (uint32_t)f.bvh.size();
+    P.bvh_f = (const DFNode*)d.bvh_f; P.filter_m = f.filter_m;
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;
@@ -585,26 +589,26 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
 
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     LaunchShape shape = pathtrace_shape(f.feats, P.flags);
-    P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth);
+    P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth, P.flags);
     // the camera-path queue: the kernel family's minimum, widened (refills at full lane occupancy) while every node still fits
     for (uint32_t q = 64u; q > shape.queue_entries; q >>= 1) {
         LaunchShape wide = shape; wide.queue_entries = q;
-        if (cached_nodes<T>(wide, f, prop, P.stack_depth) == P.n_cached) { shape = wide; break; }
+        if (cached_nodes<T>(wide, f, prop, P.stack_depth, P.flags) == P.n_cached) { shape = wide; break; }
     }
     // a tree that does not fit anyway: 32 entries when that costs the node cache less than a fifth of its nodes — a 16-entry queue runs
     // the camera code four times as often at a quarter of the lanes (5 % of a final-scene frame), and the deepest cached levels are
     // worth less (*measured* final scene, 2240 nodes + 16 entries 44.6 ms, 1920 + 32 42.7 ms, 1280 + 64 46.5 ms per 64 spp)
     if (shape.queue_entries < 32u && P.n_cached < (uint32_t)f.bvh.size()) {
         LaunchShape wide = shape; wide.queue_entries = 32u;
-        const uint32_t n32 = cached_nodes<T>(wide, f, prop, P.stack_depth);
+        const uint32_t n32 = cached_nodes<T>(wide, f, prop, P.stack_depth, P.flags);
         if ((uint64_t)n32 * 5u >= (uint64_t)P.n_cached * 4u) { shape = wide; P.n_cached = n32; }
     }
     if (const char* v = std::getenv("RT_QUEUE_ENTRIES")) {       // A/B runs only: the queue first, the node cache gets what is left
         const long n = std::strtol(v, nullptr, 10);
-        if (n == 16 || n == 32 || n == 64) { shape.queue_entries = (uint32_t)n; P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth); }
+        if (n == 16 || n == 32 || n == 64) { shape.queue_entries = (uint32_t)n; P.n_cached = cached_nodes<T>(shape, f, prop, P.stack_depth, P.flags); }
     }
     P.queue_entries = shape.queue_entries;
-    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, sizeof(DBvhNode<T>));
+    size_t shmem = pathtrace_lds_bytes(shape, P.stack_depth, P.n_cached, lds_node_bytes<T>(P.flags));
     int bpc = pathtrace_blocks_per_cu<T>(f.feats, P.flags, shmem);
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel (LDS: " + std::to_string(shmem) + " bytes per workgroup)");
     const uint64_t waves_per_block = shape.threads / 64u;
@@ -717,8 +721,8 @@ int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     int bpc;
     const uint32_t sd = stack_depth_of(s.flat, eff);
-    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd), sizeof(DBvhNode<float>)));
-    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd), sizeof(DBvhNode<double>)));
+    if (flags & RT_F32) bpc = pathtrace_blocks_per_cu<float>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<float>(shape, s.flat, prop, sd, eff), lds_node_bytes<float>(eff)));
+    else bpc = pathtrace_blocks_per_cu<double>(s.flat.feats, eff, pathtrace_lds_bytes(shape, sd, cached_nodes<double>(shape, s.flat, prop, sd, eff), lds_node_bytes<double>(eff)));
     if (bpc <= 0) return set_err("occupancy query failed for the path-tracing kernel");
     HIP_OK(hipDeviceSynchronize());
     return 0;

@@ -61,6 +61,10 @@ template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t 
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
 struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
+// Conservative f32 companion of a BVH node (same id, same skip link), what the f64 kernels' box steps read (rt_kernel.hip: "filtered walk"):
+// b = {min.x, max.x, min.y, max.y, min.z, max.z} rounded OUTWARD to f32; info = left child id (inner) or own id | FNODE_LEAF (leaf).
+struct alignas(16) DFNode { float b[6]; uint32_t skip, info; };
+static const uint32_t FNODE_LEAF = 0x40000000u;
 template <typename T> struct alignas(16) DMaterial { uint32_t kind, tex; T albedo[3]; T param; };   // metal: albedo, fuzz; dielectric: param = ir; PBR: tex = base colour, albedo[0] = index into pbr[]
 template <typename T> struct DPbr { T metallic, subsurface, specular, roughness, specular_tint, anisotropic, sheen, sheen_tint, clearcoat, clearcoat_gloss; };   // src/mat.rs:85-97
 template <typename T> struct alignas(16) DTexture { uint32_t kind, a, b, c; T color[3]; T scale; }; // check: a = odd, b = even; noise: a = perlin; image: a = byte offset, b = width, c = height
@@ -117,6 +121,9 @@ template <typename T> struct KParams {
     // debugging aid (-DRT_TRACE_PATH builds, rt_debug_trace_path): the path (trace_px, trace_s) writes 16 doubles per level to trace_out
     double* trace_out; uint32_t trace_px, trace_s;
     // (new fields go here, at the end: the list-scene kernels are sensitive to the kernel-argument layout of the fields above)
+    // filtered walk (f64 kernels, reference traversal order): the f32 companions of bvh[] — the first n_cached of THEM are what the
+    // workgroups stage in LDS then — and filter_m >= every |coordinate| of theirs (>= 1; 0 = no filter: some box is non-finite or huge)
+    const DFNode* bvh_f; float filter_m;
 };
 
 } // namespace rt

@@ -98,6 +98,13 @@
 #define RT_WW_NUM 3u
 #define RT_WW_DEN 8u
 #endif
+#ifndef RT_SPECULATE
+#define RT_SPECULATE 0
+#endif
+#ifndef RT_SPEC_NUM
+#define RT_SPEC_NUM 5u
+#define RT_SPEC_DEN 8u
+#endif
 
 namespace rt {
 
@@ -460,6 +467,121 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
     return ld_node_at(P.bvh, node);
 }
 
+// ------------------------------------------------------------------ the filtered walk (f64 kernels, reference traversal order)
+// BVH::hit (bvh.rs:77-91) tests a leaf's primitives iff the leaf's OWN box passes AABB::hit with the closest hit at that moment: every
+// ancestor's box contains the leaf's, so (monotonic rounding, see bvh_hit_spec below) it passes whenever the leaf's does — the recursion
+// is an ordered scan of the leaves, and the inner boxes only decide how much of that scan can be skipped.  Nothing about a SKIPPED
+// subtree reaches the result.  So the box steps need not run the reference's arithmetic: any test that never fails where the exact
+// test of a leaf below would pass visits the same leaves with the same closest hits, and the exact f64 test (aabb.rs:19-36) is run
+// once, on the leaf's own box, in the leaf step.  The box steps here are that: f32 slab tests on outward-rounded boxes with an error
+// margin, ~15 f32 instructions and two 16-byte LDS reads per node instead of ~45 f64 / select instructions and four reads.
+//
+// CONSERVATIVE, proof.  Ray (o, inv = 1/d as the kernel computes it, both f64), a leaf box B, a node X whose f64 box contains B, X32 its
+// outward-rounded f32 box (contains B too).  For axis j let N_j(.) / F_j(.) be the REAL near / far slab values min / max((mn_j - o_j) inv_j,
+// (mx_j - o_j) inv_j): N_j(X32) <= N_j(B), F_j(X32) >= F_j(B).  The exact test computes near_j, far_j = fl64(fl64(m - o_j) inv_j), each
+// within 2.01 * 2^-53 (|m| + |o_j|) |inv_j| of the real value, and passes iff min(c, far_x, far_y, far_z) > max(t_min, near_x, near_y, near_z).
+// The filter computes v = fma32(m32, inv32_j, s) with inv32 = rn32(inv), s = rn32(rn32(-fl64(o_j inv_j)) -/+ E_j):
+//   |m32 inv32 - m32 inv| <= u |m32| |inv|,  |rn32(-fl64(o inv)) + o inv| <= 1.01 u |o| |inv|,  the rounding of s <= 1.01 u (|o| |inv| + E_j),
+//   the fma's own rounding <= u |v| <= 1.01 u (|m32| + |o|) |inv|      (u = 2^-24; ranges below keep everything normal)
+// so v is within 3.1 u (M + |o_j|) |inv_j| + 1.01 u E_j of (m32 - o_j) inv_j -/+ E_j, where M >= every |coordinate| of every X32.  With
+// E_j = 6 u (M + |o_j|) |inv_j| (computed in f32: >= 5.99 u (..)) the near value is <= N_j(X32) <= N_j(B) <= near_j + tiny and the far value
+// >= F_j(X32) >= far_j - tiny, "tiny" (2^-52 (..)) being covered by the slack left in E_j.  With c32 >= c and tmin32 <= t_min (rounded
+// away and bumped by an ulp), min(c32, far'..) >= min(c, far..) and max(tmin32, near'..) <= max(t_min, near..): exact pass => filter pass.
+// Ranges (else the wave takes the exact walk): o, inv finite, |o_j| <= 2^40, 2^-40 <= |inv_j| <= 2^40, every box finite, min <= max,
+// M <= 2^40 (host: KParams::filter_m, >= 1): products stay below 2^82 and E_j above 2^-62, so no overflow, and an underflow (< 2^-126)
+// anywhere is far inside E_j.  A NaN closest hit (never seen) converts to a quiet NaN, which v_min_f32 ignores: conservative.
+struct BoxFilter { float ix, iy, iz, ax, bx, ay, by, az, bz, tmin, c; bool ok; };
+DEV float max3_nn(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV float min3_nn(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV float up32(double x) { x = x < -3.0e38 ? -3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f); }      // >= x
+DEV float down32(double x) { x = x > 3.0e38 ? 3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f); }   // <= x
+DEV BoxFilter make_filter(float M, V3<double> o, V3<double> inv, double t_min, double closest) {
+    BoxFilter F;
+    F.ix = (float)inv.x; F.iy = (float)inv.y; F.iz = (float)inv.z;
+    const float jx = __builtin_fabsf(F.ix), jy = __builtin_fabsf(F.iy), jz = __builtin_fabsf(F.iz);
+    const float ox = __builtin_fabsf((float)o.x), oy = __builtin_fabsf((float)o.y), oz = __builtin_fabsf((float)o.z);
+    F.ok = M > 0.0f && max3_nn(jx, jy, jz) <= 0x1p40f && min3_nn(jx, jy, jz) >= 0x1p-40f && max3_nn(ox, oy, oz) <= 0x1p40f;
+    const float K = 6.0f * 0x1p-24f;
+    const float ex = __builtin_copysignf((M + ox) * jx * K, F.ix), ey = __builtin_copysignf((M + oy) * jy * K, F.iy), ez = __builtin_copysignf((M + oz) * jz * K, F.iz);
+    const float nx = (float)(-(o.x * inv.x)), ny = (float)(-(o.y * inv.y)), nz = (float)(-(o.z * inv.z));
+    // the min plane is the near one where inv > 0: it gets -E, the max plane +E; the other way round where inv < 0 (the sign rides on E)
+    F.ax = nx - ex; F.bx = nx + ex; F.ay = ny - ey; F.by = ny + ey; F.az = nz - ez; F.bz = nz + ez;
+    F.tmin = down32(t_min); F.c = up32(closest);
+    return F;
+}
+DEV bool filter_pass(const DFNode& nd, const BoxFilter& F) {
+    const float a0 = __builtin_fmaf(nd.b[0], F.ix, F.ax), b0 = __builtin_fmaf(nd.b[1], F.ix, F.bx);
+    const float a1 = __builtin_fmaf(nd.b[2], F.iy, F.ay), b1 = __builtin_fmaf(nd.b[3], F.iy, F.by);
+    const float a2 = __builtin_fmaf(nd.b[4], F.iz, F.az), b2 = __builtin_fmaf(nd.b[5], F.iz, F.bz);
+    const float t_in = max_nn(max3_nn(min_nn(a0, b0), min_nn(a1, b1), min_nn(a2, b2)), F.tmin);
+    const float t_o = min_nn(min3_nn(max_nn(a0, b0), max_nn(a1, b1), max_nn(a2, b2)), F.c);
+    return !(t_o < t_in);
+}
+// a filter node: LDS for the ids the workgroup staged (depth order: the top levels, or the whole tree), else global memory
+template <typename T> DEV DFNode fetch_fnode(const KParams<T>& P, uint32_t node) {
+    if (node < P.n_cached) return *(const DFNode*)(lds_raw + node * (uint32_t)sizeof(DFNode));
+    return ld_record((const DFNode*)((const char*)P.bvh_f + (size_t)(node * (uint32_t)sizeof(DFNode))));
+}
+template <typename T> DEV uint32_t fnode_skip(const KParams<T>& P, uint32_t node) {
+    if (node < P.n_cached) return *(const uint32_t*)(lds_raw + node * (uint32_t)sizeof(DFNode) + 24u);
+    return cl((const uint32_t*)((const char*)P.bvh_f + (size_t)(node * (uint32_t)sizeof(DFNode)) + 24u));
+}
+// which instantiations walk this way (the host sizes the LDS node cache by the same rule: rt_launch.h filtered_walk)
+template <typename T, uint32_t FEATS> struct Filt { static constexpr bool on = sizeof(T) == 8u && (FEATS & F_BVH) != 0u && (FEATS & F_NEAR_FIRST) == 0u; };
+
+// One lane's state is ONE word: the node it stands at; | FNODE_LEAF: a leaf whose box the filter passed, waiting for the leaf step;
+// DONE.  Box steps and leaf steps are chosen by vote as in bvh_hit_ww.  SPEC (worlds that are one BVH, every lane walks): a lane does
+// not wait with one pending leaf, it walks on with its closest hit as it is and waits with two — every leaf is tested against its own
+// box with the closest hit of THAT moment in the leaf step anyway, so walking ahead with a stale (larger) bound only visits more.
+// Untamed waves (a ray or a scene outside the filter's ranges; rare) run AABB::hit's exact form on the f64 nodes in the same loop.
+template <uint32_t FEATS, bool SPEC>
+DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out) {
+    const V3<double> inv = mk<double>(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
+    double closest = t_max;
+    bool any = false;
+    const uint32_t DONE = 0xFFFFFFFFu;
+    BoxFilter F = make_filter(P.filter_m, ray.o, inv, t_min, closest);
+    const bool tame = P.bvh_tame != 0u && __ballot(!(ray_is_tame(ray.o, inv) && F.ok)) == 0ull;   // wave-uniform: every lane of this search
+    uint32_t node = root, p1 = DONE;                   // SPEC: p1 = the older pending leaf (id), `node` may hold a second one
+    for (;;) {
+        for (;;) {
+            const bool want_box = node < FNODE_LEAF;
+            const bool pending = SPEC ? p1 != DONE : (int32_t)node >= (int32_t)FNODE_LEAF;
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(pending));
+            const uint32_t n_act = SPEC ? (uint32_t)__popcll(__ballot(node != DONE || p1 != DONE)) : n_box + n_leaf;
+            if (n_box == 0u || n_leaf * (SPEC ? RT_SPEC_DEN : RT_WW_DEN) >= n_act * (SPEC ? RT_SPEC_NUM : RT_WW_NUM)) break;
+            auto box_step = [&]() {
+                if (tame) {
+                    const DFNode nd = fetch_fnode(P, node);
+                    const bool pass = filter_pass(nd, F);
+                    const bool ahead = SPEC && pass && (nd.info & FNODE_LEAF) != 0u && p1 == DONE;      // first pending leaf: remember it, walk on
+                    if (ahead) p1 = node;
+                    node = (pass && !ahead) ? nd.info : nd.skip;
+                } else {
+                    const DBvhNode<double> nd = ld_node_at(P.bvh, node);
+                    node = box_inside_exact(nd, ray.o, inv, t_min, closest) ? ((nd.a & BVH_LEAF) ? (node | FNODE_LEAF) : nd.c) : nd.skip;
+                }
+            };
+            if (want_box) box_step();
+#pragma unroll
+            for (int k = 1; k < RT_BOX_STEPS; k++) if (node < FNODE_LEAF) box_step();
+        }
+        const uint32_t leaf = SPEC ? (p1 != DONE ? p1 : ((int32_t)node >= (int32_t)FNODE_LEAF ? node & ~FNODE_LEAF : DONE))
+                                   : ((int32_t)node >= (int32_t)FNODE_LEAF ? node & ~FNODE_LEAF : DONE);
+        if (leaf != DONE) {
+            const DBvhNode<double> lf = ld_node_at(P.bvh, leaf);
+            double t; uint32_t prim;
+            if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
+                range_hit<double, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
+            if (SPEC && p1 != DONE) { p1 = DONE; if ((int32_t)node >= (int32_t)FNODE_LEAF) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
+            else node = lf.skip;
+        }
+        if (__ballot(node != DONE || (SPEC && p1 != DONE)) == 0ull) break;
+    }
+    t_out = closest;
+    return any;
+}
+
 // `root` is the node a lane's walk starts at.
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
@@ -537,13 +659,6 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
 // tree — +1.6 / +2.1 / +2.6 (5/8) / +2.3 / -5 %; final scene -3 %, teapot room in lock-step -3 % (few lanes enter: the waiting it removes is
 // a fifth of the box steps' lane-slots and half of what it walks instead is wasted).  So it has its own instantiation (F_SPEC), chosen
 // by the host for scenes whose world is one BVH; -DRT_SPECULATE=1 turns it on in every lock-step BVH kernel (measurement builds).
-#ifndef RT_SPECULATE
-#define RT_SPECULATE 0
-#endif
-#ifndef RT_SPEC_NUM
-#define RT_SPEC_NUM 5u
-#define RT_SPEC_DEN 8u
-#endif
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
     const V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
@@ -586,6 +701,7 @@ DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
 
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
+    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<FEATS, (RT_SPECULATE || (FEATS & F_SPEC)) != 0u>(P, root, ray, t_min, t_max, t_out, prim_out);
     if ((RT_SPECULATE || (FEATS & F_SPEC)) && !(FEATS & F_NEAR_FIRST)) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
     return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack);
 }
@@ -1664,7 +1780,10 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             }
             const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);      // AABB::hit's 1/d (aabb.rs:21), same value at every node
             const T t_min = TMin<T>::v();
-            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !ray_is_tame(r.o, inv)) == 0ull;   // wave-uniform, this pass
+            constexpr bool FILT = Filt<T, FEATS>::on;                  // the filtered walk (bvh_hit_filt): tv_node | FNODE_LEAF = pending leaf
+            BoxFilter F; F.ok = true;
+            if constexpr (FILT) F = make_filter(P.filter_m, r.o, inv, t_min, tv_closest);
+            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !(ray_is_tame(r.o, inv) && F.ok)) == 0ull;   // wave-uniform, this pass
             uint32_t stop_below = n_bvh * 3u / 4u;                  // entered below trav_hi (nothing else to do): until a quarter has finished
             if (stop_below > P.trav_lo) stop_below = P.trav_lo;
             if (stop_below < 1u) stop_below = 1u;
@@ -1677,12 +1796,21 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             for (;;) {
                 bool few = false;
                 for (;;) {
-                    const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
-                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(act && tv_have_leaf));
+                    const bool want_box = FILT ? act && tv_node < FNODE_LEAF : act && !tv_have_leaf && tv_node != BVH_DONE;
+                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)),
+                                   n_leaf = (uint32_t)__popcll(__ballot(FILT ? act && (int32_t)tv_node >= (int32_t)FNODE_LEAF : act && tv_have_leaf));
                     few = n_box + n_leaf < stop_below;
                     if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
                     n_steps++; n_step_lanes += n_box;
                     auto box_step = [&]() {
+                        if constexpr (FILT) {
+                            if (tame) { const DFNode nd = fetch_fnode(P, tv_node); tv_node = filter_pass(nd, F) ? nd.info : nd.skip; }
+                            else {
+                                const DBvhNode<T> nd = ld_node_at(P.bvh, tv_node);
+                                tv_node = box_inside_exact(nd, r.o, inv, t_min, tv_closest) ? ((nd.a & BVH_LEAF) ? (tv_node | FNODE_LEAF) : nd.c) : nd.skip;
+                            }
+                            return;
+                        }
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
                         if (!near_first) {                                    // threaded preorder walk (bvh_hit_ww)
@@ -1705,14 +1833,23 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                     if (want_box) box_step();
 #pragma unroll
                     for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote (bvh_hit_ww)
-                        const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
+                        const bool more = FILT ? act && tv_node < FNODE_LEAF : act && !tv_have_leaf && tv_node != BVH_DONE;
                         n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
                         if (more) box_step();
                     }
                 }
                 if (few) break;                                   // (pending leaves wait for the next traversal pass)
                 DIAG_ADD(0);
-                n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(act && tv_have_leaf));
+                n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(FILT ? act && (int32_t)tv_node >= (int32_t)FNODE_LEAF : act && tv_have_leaf));
+                if constexpr (FILT) {
+                    if (act && (int32_t)tv_node >= (int32_t)FNODE_LEAF) {
+                        const DBvhNode<T> lf = ld_node_at(P.bvh, tv_node & ~FNODE_LEAF);
+                        T t; uint32_t prim;
+                        if ((!tame || box_inside_tame(lf, r.o, inv, t_min, tv_closest)) &&           // aabb.rs:19-36 on the leaf's own box
+                            range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; F.c = up32(tv_closest); }
+                        tv_node = lf.skip;
+                    }
+                } else
                 if (act && tv_have_leaf) {
                     T t; uint32_t prim;
                     if (!near_first) {
@@ -1725,7 +1862,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 }
                 DIAG_ADD(5);
             }
-            if (act && !tv_have_leaf && tv_node == BVH_DONE) {
+            if (act && !tv_have_leaf && tv_node == BVH_DONE) {       // (filtered walk: a pending leaf is tv_node | FNODE_LEAF, never BVH_DONE)
                 // ---- this BVH is done: its result joins the list search (hit.rs:62-69), the lane moves to the next object
                 if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
                 my_oi++;
@@ -1810,14 +1947,14 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
     // dynamic LDS: [n_cached BVH nodes] [WAVES][regen_bytes(queue_entries)] camera-path queues [WAVES][stack_depth][64] BVH stacks
     typedef Shape<FEATS> S;
     const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
-    const uint32_t nodes_bytes = P.n_cached * (uint32_t)sizeof(DBvhNode<T>);
+    const uint32_t nodes_bytes = P.n_cached * (uint32_t)(Filt<T, FEATS>::on ? sizeof(DFNode) : sizeof(DBvhNode<T>));
     if ((FEATS & F_BVH) && P.n_cached != 0u) {
         // the top of the BVH, once per workgroup: 16-byte pieces, consecutive threads consecutive pieces; the only barrier of the kernel.
         // (Round 3: one 16-byte slot of padding per node, so that the k-th pieces of different nodes spread over all sixteen slots of the
         // LDS bank row instead of four, was measured and is not faster — random spheres -1.4 %, final scene -1.5 %, teapot room -6 %, whose
         // tree then no longer fits: bank conflicts are not what a step waits for.)
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
-        const u4* src = (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
+        const u4* src = Filt<T, FEATS>::on ? (const u4*)P.bvh_f : (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
         for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
         __syncthreads();
     }

@@ -28,6 +28,8 @@ struct HostFlat {             // canonical f64 flattening
     std::vector<DMSphere<double>> mspheres;
     std::vector<DTri<double>> tris;
     std::vector<DBvhNode<double>> bvh;
+    std::vector<DFNode> bvh_f;     // f32 companions of bvh[] for the filtered walk (boxes rounded outward; rt_flatten.cpp: make_filter_nodes)
+    float filter_m = 0.0f;         // >= every |coordinate| in bvh_f, >= 1; 0: no filter (a box is not finite, inverted, or beyond 2^40)
     std::vector<DMaterial<double>> materials;
     std::vector<DTexture<double>> textures;
     std::vector<DMedium<double>> media;
@@ -41,7 +43,7 @@ template <typename T> struct DeviceScene {   // device copies of HostFlat for on
     bool valid = false;
     void* objects = nullptr; void* ops = nullptr; void* rects = nullptr; void* spheres = nullptr; void* mspheres = nullptr;
     void* tris = nullptr; void* bvh = nullptr; void* materials = nullptr; void* textures = nullptr; void* media = nullptr;
-    void* lights = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr;
+    void* lights = nullptr; void* perlins = nullptr; void* image = nullptr; void* pbr = nullptr; void* bvh_f = nullptr;
 };
 
 struct Scene {
