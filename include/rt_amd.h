@@ -198,7 +198,7 @@ int rt_last_multi_ms(rt_scene*, double out4[4]);
 enum rt_bvh_builder { RT_BVH_MEDIAN = 0, RT_BVH_SAH = 1 };
 /* Tuning knob of the persistent-traversal loop (scheduling only, never results): a traversal pass starts once `start_at` lanes of a
  * wavefront are inside a BVH and runs until fewer than `stop_below` are still walking; primitives are tested once `leaf_share64`/64
- * of the walking lanes hold a pending leaf.  Defaults 40, 24, 24 (measured best on the teapot room; the optimum is flat). */
+ * of the walking lanes hold a pending leaf.  Defaults 56, 16, 32 (measured best on the teapot room; the optimum is flat). */
 int rt_scene_set_traversal_schedule(rt_scene*, uint32_t start_at, uint32_t stop_below, uint32_t leaf_share64);
 int rt_scene_set_bvh_builder(rt_scene*, int mode);
 /* Optional: do now what the first render of this scene would do once inside its call (flatten, upload for the precision in

@@ -2,6 +2,8 @@
 // flat device scene of rt_ir.h; BVH build (src/bvh.rs:18-73), Camera::new (src/camera.rs:19-49).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <functional>
@@ -429,6 +431,30 @@ void make_filter_nodes(HostFlat& f) {
         o.info = (nd.a & BVH_LEAF) ? ((uint32_t)i | FNODE_LEAF) : nd.c;
     }
     if (ok && m <= 0x1p40f) f.filter_m = m;
+    // Contraction.  By the ordered-scan form of BVH::hit (rt_kernel.hip: the filtered walk) ANY conservative hierarchy over the leaves in
+    // the reference's order gives the reference's samples.  An inner node whose box is nearly its parent's almost always passes when the
+    // parent does — its test buys nothing — so it leaves the filter tree: every link to it goes to its left child instead (its right
+    // child is already where the left subtree's skip links lead, and what follows the right subtree is what followed the node).  The
+    // f64 nodes keep the reference's tree (exact walk of untamed waves).  Area ratio above which a node goes: *measured* (round 5,
+    // profiles/r05_collapse_sweep.log) 0.5 — the break-even if a box were hit in proportion to its area — is far too eager (final scene
+    // 2.5x slower: rays are culled by the closest hit, not by area), 0.7 - 0.8 is best on all three BVH scenes (+2 ... +4 %).
+    double tau = 0.75;
+    if (const char* v = std::getenv("RT_COLLAPSE_TAU")) tau = std::atof(v);       // A/B runs only (>= 1: no contraction)
+    auto area = [&](const DBvhNode<double>& b) { const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
+    std::vector<uint32_t> parent(n, 0xFFFFFFFFu), redirect(n);
+    for (size_t i = 0; i < n; i++) if (!(f.bvh[i].a & BVH_LEAF)) { parent[f.bvh[i].c] = (uint32_t)i; parent[f.bvh[i].b] = (uint32_t)i; }
+    for (size_t i = 0; i < n; i++) {
+        redirect[i] = (uint32_t)i;
+        if ((f.bvh[i].a & BVH_LEAF) || parent[i] == 0xFFFFFFFFu) continue;       // leaves and roots stay
+        const double ap = area(f.bvh[parent[i]]);
+        if (ap > 0.0 && area(f.bvh[i]) > tau * ap) redirect[i] = f.bvh[i].c;
+    }
+    auto resolve = [&](uint32_t x) { while (x != 0xFFFFFFFFu && redirect[x] != x) x = redirect[x]; return x; };
+    for (size_t i = 0; i < n; i++) {
+        DFNode& o = f.bvh_f[i];
+        o.skip = resolve(o.skip);
+        if (!(o.info & FNODE_LEAF)) o.info = resolve(o.info);
+    }
 }
 
 } // namespace

@@ -95,7 +95,7 @@
 #define RT_WAVES_PBR 3
 #endif
 #ifndef RT_WW_NUM
-#define RT_WW_NUM 3u
+#define RT_WW_NUM 5u      // (3/8 until the filtered walk made box steps cheap: final scene +2 ... +5 % at 5/8, profiles/r05_ww_vote_ab.log)
 #define RT_WW_DEN 8u
 #endif
 #ifndef RT_SPECULATE
@@ -507,76 +507,107 @@ DEV BoxFilter make_filter(float M, V3<double> o, V3<double> inv, double t_min, d
     // the min plane is the near one where inv > 0: it gets -E, the max plane +E; the other way round where inv < 0 (the sign rides on E)
     F.ax = nx - ex; F.bx = nx + ex; F.ay = ny - ey; F.by = ny + ey; F.az = nz - ez; F.bz = nz + ez;
     F.tmin = down32(t_min); F.c = up32(closest);
+    asm volatile("" : "+v"(F.tmin));      // a register, not a literal re-materialised in every box step
     return F;
 }
 DEV bool filter_pass(const DFNode& nd, const BoxFilter& F) {
     const float a0 = __builtin_fmaf(nd.b[0], F.ix, F.ax), b0 = __builtin_fmaf(nd.b[1], F.ix, F.bx);
     const float a1 = __builtin_fmaf(nd.b[2], F.iy, F.ay), b1 = __builtin_fmaf(nd.b[3], F.iy, F.by);
     const float a2 = __builtin_fmaf(nd.b[4], F.iz, F.az), b2 = __builtin_fmaf(nd.b[5], F.iz, F.bz);
+#ifdef RT_EXP_BUILTIN_MM
+    const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, b0), __builtin_fminf(a1, b1)), __builtin_fminf(a2, b2)), F.tmin);
+    const float t_o = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(a1, b1)), __builtin_fmaxf(a2, b2)), F.c);
+#else
     const float t_in = max_nn(max3_nn(min_nn(a0, b0), min_nn(a1, b1), min_nn(a2, b2)), F.tmin);
     const float t_o = min_nn(min3_nn(max_nn(a0, b0), max_nn(a1, b1), max_nn(a2, b2)), F.c);
+#endif
     return !(t_o < t_in);
 }
-// a filter node: LDS for the ids the workgroup staged (depth order: the top levels, or the whole tree), else global memory
-template <typename T> DEV DFNode fetch_fnode(const KParams<T>& P, uint32_t node) {
-    if (node < P.n_cached) return *(const DFNode*)(lds_raw + node * (uint32_t)sizeof(DFNode));
-    return ld_record((const DFNode*)((const char*)P.bvh_f + (size_t)(node * (uint32_t)sizeof(DFNode))));
+// Where a walk stands is one word per lane, a STATE: a node (box step next) | a leaf's id with FNODE_LEAF set (its box passed the
+// filter: leaf step next) | ST_DONE.  When the whole tree is in LDS (KParams::n_cached == n_bvh: every BASELINE scene) the staged copy's
+// links are LDS ADDRESSES (pathtrace_kernel rewrites them while it stages) and so is a node state: a box step is then two ds_read_b128
+// at the state itself, no shift, no base, no cached-or-not test.  Otherwise states are node ids and fetch_fnode picks LDS or memory.
+static const uint32_t ST_DONE = 0xFFFFFFFFu;
+typedef __attribute__((address_space(3))) const unsigned char* lds_cptr;
+DEV uint32_t lds_base() { return (uint32_t)(size_t)(lds_cptr)lds_raw; }
+template <typename T> DEV bool all_in_lds(const KParams<T>& P) { return P.n_cached >= P.n_bvh; }
+template <typename T> DEV uint32_t state_of(const KParams<T>& P, uint32_t id) { return id == ST_DONE ? ST_DONE : (all_in_lds(P) ? lds_base() + id * (uint32_t)sizeof(DFNode) : id); }
+template <typename T> DEV uint32_t id_of(const KParams<T>& P, uint32_t state) { return all_in_lds(P) ? (state - lds_base()) / (uint32_t)sizeof(DFNode) : state; }
+DEV bool st_walking(uint32_t st) { return st < FNODE_LEAF; }
+DEV bool st_pending(uint32_t st) { return (int32_t)st >= (int32_t)FNODE_LEAF; }          // (ST_DONE is negative)
+template <bool ALL, typename T> DEV DFNode fetch_fnode(const KParams<T>& P, uint32_t st) {
+    if (ALL) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) const u4* lds_u4;
+        DFNode nd;
+        *(u4*)&nd = *(lds_u4)(size_t)st; *((u4*)&nd + 1) = *((lds_u4)(size_t)st + 1);
+        return nd;
+    }
+    if (st < P.n_cached) return *(const DFNode*)(lds_raw + st * (uint32_t)sizeof(DFNode));
+    return ld_record((const DFNode*)((const char*)P.bvh_f + (size_t)(st * (uint32_t)sizeof(DFNode))));
 }
-template <typename T> DEV uint32_t fnode_skip(const KParams<T>& P, uint32_t node) {
-    if (node < P.n_cached) return *(const uint32_t*)(lds_raw + node * (uint32_t)sizeof(DFNode) + 24u);
-    return cl((const uint32_t*)((const char*)P.bvh_f + (size_t)(node * (uint32_t)sizeof(DFNode)) + 24u));
+// the state a walk moves to once leaf `id` is finished (the leaf's skip link, in the form states have in this launch)
+template <typename T> DEV uint32_t fnode_skip(const KParams<T>& P, uint32_t id) {
+    if (id < P.n_cached) return *(const uint32_t*)(lds_raw + id * (uint32_t)sizeof(DFNode) + 24u);
+    return cl((const uint32_t*)((const char*)P.bvh_f + (size_t)(id * (uint32_t)sizeof(DFNode)) + 24u));
+}
+// AABB::hit's exact form on an f64 node, as a state transition (untamed waves only: a ray or a scene outside the filter's ranges)
+template <typename T> DEV uint32_t exact_step(const KParams<T>& P, uint32_t st, V3<T> o, V3<T> inv, T t_min, T closest) {
+    const uint32_t id = id_of(P, st);
+    const DBvhNode<T> nd = ld_node_at(P.bvh, id);
+    if (!box_inside_exact(nd, o, inv, t_min, closest)) return state_of(P, nd.skip);
+    return (nd.a & BVH_LEAF) ? (id | FNODE_LEAF) : state_of(P, nd.c);
 }
 // which instantiations walk this way (the host sizes the LDS node cache by the same rule: rt_launch.h filtered_walk)
 template <typename T, uint32_t FEATS> struct Filt { static constexpr bool on = sizeof(T) == 8u && (FEATS & F_BVH) != 0u && (FEATS & F_NEAR_FIRST) == 0u; };
 
-// One lane's state is ONE word: the node it stands at; | FNODE_LEAF: a leaf whose box the filter passed, waiting for the leaf step;
-// DONE.  Box steps and leaf steps are chosen by vote as in bvh_hit_ww.  SPEC (worlds that are one BVH, every lane walks): a lane does
-// not wait with one pending leaf, it walks on with its closest hit as it is and waits with two — every leaf is tested against its own
-// box with the closest hit of THAT moment in the leaf step anyway, so walking ahead with a stale (larger) bound only visits more.
-// Untamed waves (a ray or a scene outside the filter's ranges; rare) run AABB::hit's exact form on the f64 nodes in the same loop.
+// Box steps and leaf steps are chosen by vote as in bvh_hit_ww.  SPEC (worlds that are one BVH: every lane walks): a lane does not wait
+// with one pending leaf, it walks on with its closest hit as it is and waits with two — every leaf is tested against its own box with
+// the closest hit of THAT moment in the leaf step anyway, so walking ahead with a stale (larger) bound only visits more.
 template <uint32_t FEATS, bool SPEC>
 DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out) {
     const V3<double> inv = mk<double>(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
     double closest = t_max;
     bool any = false;
-    const uint32_t DONE = 0xFFFFFFFFu;
     BoxFilter F = make_filter(P.filter_m, ray.o, inv, t_min, closest);
     const bool tame = P.bvh_tame != 0u && __ballot(!(ray_is_tame(ray.o, inv) && F.ok)) == 0ull;   // wave-uniform: every lane of this search
-    uint32_t node = root, p1 = DONE;                   // SPEC: p1 = the older pending leaf (id), `node` may hold a second one
-    for (;;) {
+    uint32_t node = state_of(P, root), p1 = ST_DONE;       // SPEC: p1 = the older pending leaf (id); `node` may hold a second one
+    auto box_steps = [&](auto all) {
+        constexpr bool ALL = decltype(all)::value;
         for (;;) {
-            const bool want_box = node < FNODE_LEAF;
-            const bool pending = SPEC ? p1 != DONE : (int32_t)node >= (int32_t)FNODE_LEAF;
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(pending));
-            const uint32_t n_act = SPEC ? (uint32_t)__popcll(__ballot(node != DONE || p1 != DONE)) : n_box + n_leaf;
+            const bool want_box = st_walking(node);
+            const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(SPEC ? p1 != ST_DONE : st_pending(node)));
+            const uint32_t n_act = SPEC ? (uint32_t)__popcll(__ballot(node != ST_DONE || p1 != ST_DONE)) : n_box + n_leaf;
             if (n_box == 0u || n_leaf * (SPEC ? RT_SPEC_DEN : RT_WW_DEN) >= n_act * (SPEC ? RT_SPEC_NUM : RT_WW_NUM)) break;
             auto box_step = [&]() {
-                if (tame) {
-                    const DFNode nd = fetch_fnode(P, node);
-                    const bool pass = filter_pass(nd, F);
-                    const bool ahead = SPEC && pass && (nd.info & FNODE_LEAF) != 0u && p1 == DONE;      // first pending leaf: remember it, walk on
-                    if (ahead) p1 = node;
-                    node = (pass && !ahead) ? nd.info : nd.skip;
-                } else {
-                    const DBvhNode<double> nd = ld_node_at(P.bvh, node);
-                    node = box_inside_exact(nd, ray.o, inv, t_min, closest) ? ((nd.a & BVH_LEAF) ? (node | FNODE_LEAF) : nd.c) : nd.skip;
-                }
+                const DFNode nd = fetch_fnode<ALL>(P, node);
+                const bool pass = filter_pass(nd, F);
+                const bool ahead = SPEC && pass && (nd.info & FNODE_LEAF) != 0u && p1 == ST_DONE;      // first pending leaf: remember it, walk on
+                if (ahead) p1 = nd.info & ~FNODE_LEAF;
+                node = (pass && !ahead) ? nd.info : nd.skip;
             };
             if (want_box) box_step();
 #pragma unroll
-            for (int k = 1; k < RT_BOX_STEPS; k++) if (node < FNODE_LEAF) box_step();
+            for (int k = 1; k < RT_BOX_STEPS; k++) if (st_walking(node)) box_step();
         }
-        const uint32_t leaf = SPEC ? (p1 != DONE ? p1 : ((int32_t)node >= (int32_t)FNODE_LEAF ? node & ~FNODE_LEAF : DONE))
-                                   : ((int32_t)node >= (int32_t)FNODE_LEAF ? node & ~FNODE_LEAF : DONE);
-        if (leaf != DONE) {
+    };
+    for (;;) {
+        if (tame) { if (all_in_lds(P)) box_steps(std::true_type()); else box_steps(std::false_type()); }
+        else while (__ballot(st_walking(node)) != 0ull) { if (st_walking(node)) node = exact_step(P, node, ray.o, inv, t_min, closest); }   // to every lane's next leaf
+        const uint32_t leaf = (SPEC && p1 != ST_DONE) ? p1 : (st_pending(node) ? node & ~FNODE_LEAF : ST_DONE);
+        if (leaf != ST_DONE) {
             const DBvhNode<double> lf = ld_node_at(P.bvh, leaf);
             double t; uint32_t prim;
+#ifdef RT_EXP_NO_LEAF_BOX
+            if (
+#else
             if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
+#endif
                 range_hit<double, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
-            if (SPEC && p1 != DONE) { p1 = DONE; if ((int32_t)node >= (int32_t)FNODE_LEAF) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
-            else node = lf.skip;
+            if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
+            else node = fnode_skip(P, leaf);
         }
-        if (__ballot(node != DONE || (SPEC && p1 != DONE)) == 0ull) break;
+        if (__ballot(node != ST_DONE || (SPEC && p1 != ST_DONE)) == 0ull) break;
     }
     t_out = closest;
     return any;
@@ -801,7 +832,7 @@ DEV bool world_hit(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T
             RayT<T> r = ray;
             for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
             const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);
-            dl[ob.n_ops ? 1 : 0] += (unsigned long long)__popcll(__ballot(box_inside_exact(fetch_node(P, ob.geom_first), r.o, inv, t_min, closest)));
+            dl[ob.n_ops ? 1 : 0] += (unsigned long long)__popcll(__ballot(box_inside_exact(ld_node_at(P.bvh, ob.geom_first), r.o, inv, t_min, closest)));
         }
 #endif
         object_hit<T, FEATS>(P, oi, ob, ray, t_min, rng, closest, id, any, stack);
@@ -1779,11 +1810,68 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 if (here) for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
             }
             const V3<T> inv = mk<T>(T(1.0) / r.d.x, T(1.0) / r.d.y, T(1.0) / r.d.z);      // AABB::hit's 1/d (aabb.rs:21), same value at every node
+            if constexpr (Filt<T, FEATS>::on) {
+                // ---- the filtered walk (bvh_hit_filt), resumable: tv_node is the lane's state word, across passes too
+                const T t_min = TMin<T>::v();
+                const bool act = phase == PH_BVH;
+                BoxFilter F = make_filter(P.filter_m, r.o, inv, t_min, tv_closest);
+                const bool tame = P.bvh_tame != 0u && __ballot(act && !(ray_is_tame(r.o, inv) && F.ok)) == 0ull;   // wave-uniform, this pass
+                uint32_t stop_below = n_bvh * 3u / 4u;              // entered below trav_hi (nothing else to do): until a quarter has finished
+                if (stop_below > P.trav_lo) stop_below = P.trav_lo;
+                if (stop_below < 1u) stop_below = 1u;
+                bool few = false;
+                auto box_steps = [&](auto all) {
+                    constexpr bool ALL = decltype(all)::value;
+                    for (;;) {
+                        const bool want_box = act && st_walking(tv_node);
+                        const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(act && st_pending(tv_node)));
+                        few = n_box + n_leaf < stop_below;
+                        if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
+                        n_steps++; n_step_lanes += n_box;
+                        auto box_step = [&]() { const DFNode nd = fetch_fnode<ALL>(P, tv_node); tv_node = filter_pass(nd, F) ? nd.info : nd.skip; };
+                        if (want_box) box_step();
+#pragma unroll
+                        for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote
+                            const bool more = act && st_walking(tv_node);
+                            n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
+                            if (more) box_step();
+                        }
+                    }
+                };
+                for (;;) {
+                    if (tame) { if (all_in_lds(P)) box_steps(std::true_type()); else box_steps(std::false_type()); }
+                    else {
+                        while (__ballot(act && st_walking(tv_node)) != 0ull) { if (act && st_walking(tv_node)) tv_node = exact_step(P, tv_node, r.o, inv, t_min, tv_closest); }
+                        few = (uint32_t)__popcll(__ballot(act && st_pending(tv_node))) < stop_below;
+                    }
+                    if (few) break;                               // (pending leaves wait for the next traversal pass)
+                    DIAG_ADD(0);
+                    n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(act && st_pending(tv_node)));
+                    if (act && st_pending(tv_node)) {
+                        const uint32_t leaf = tv_node & ~FNODE_LEAF;
+                        const DBvhNode<T> lf = ld_node_at(P.bvh, leaf);
+                        T t; uint32_t prim;
+#ifdef RT_EXP_NO_LEAF_BOX
+                        if (
+#else
+                        if ((!tame || box_inside_tame(lf, r.o, inv, t_min, tv_closest)) &&           // aabb.rs:19-36 on the leaf's own box
+#endif
+                            range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; F.c = up32(tv_closest); }
+                        tv_node = fnode_skip(P, leaf);
+                    }
+                    DIAG_ADD(5);
+                }
+                if (act && tv_node == ST_DONE) {
+                    // ---- this BVH is done: its result joins the list search (hit.rs:62-69), the lane moves to the next object
+                    if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
+                    my_oi++;
+                    phase = PH_OBJ;
+                }
+                DIAG_ADD(0);
+                continue;
+            }
             const T t_min = TMin<T>::v();
-            constexpr bool FILT = Filt<T, FEATS>::on;                  // the filtered walk (bvh_hit_filt): tv_node | FNODE_LEAF = pending leaf
-            BoxFilter F; F.ok = true;
-            if constexpr (FILT) F = make_filter(P.filter_m, r.o, inv, t_min, tv_closest);
-            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !(ray_is_tame(r.o, inv) && F.ok)) == 0ull;   // wave-uniform, this pass
+            const bool tame = P.bvh_tame != 0u && __ballot(phase == PH_BVH && !ray_is_tame(r.o, inv)) == 0ull;   // wave-uniform, this pass
             uint32_t stop_below = n_bvh * 3u / 4u;                  // entered below trav_hi (nothing else to do): until a quarter has finished
             if (stop_below > P.trav_lo) stop_below = P.trav_lo;
             if (stop_below < 1u) stop_below = 1u;
@@ -1796,21 +1884,12 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             for (;;) {
                 bool few = false;
                 for (;;) {
-                    const bool want_box = FILT ? act && tv_node < FNODE_LEAF : act && !tv_have_leaf && tv_node != BVH_DONE;
-                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)),
-                                   n_leaf = (uint32_t)__popcll(__ballot(FILT ? act && (int32_t)tv_node >= (int32_t)FNODE_LEAF : act && tv_have_leaf));
+                    const bool want_box = act && !tv_have_leaf && tv_node != BVH_DONE;
+                    const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(act && tv_have_leaf));
                     few = n_box + n_leaf < stop_below;
                     if (few || n_box == 0u || n_leaf * 64u >= P.trav_leaf * (n_box + n_leaf)) break;
                     n_steps++; n_step_lanes += n_box;
                     auto box_step = [&]() {
-                        if constexpr (FILT) {
-                            if (tame) { const DFNode nd = fetch_fnode(P, tv_node); tv_node = filter_pass(nd, F) ? nd.info : nd.skip; }
-                            else {
-                                const DBvhNode<T> nd = ld_node_at(P.bvh, tv_node);
-                                tv_node = box_inside_exact(nd, r.o, inv, t_min, tv_closest) ? ((nd.a & BVH_LEAF) ? (tv_node | FNODE_LEAF) : nd.c) : nd.skip;
-                            }
-                            return;
-                        }
                         const DBvhNode<T> nd = fetch_node(P, tv_node);
                         const bool inside = tame ? box_inside_tame(nd, r.o, inv, t_min, tv_closest) : box_inside_exact(nd, r.o, inv, t_min, tv_closest);
                         if (!near_first) {                                    // threaded preorder walk (bvh_hit_ww)
@@ -1833,23 +1912,14 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                     if (want_box) box_step();
 #pragma unroll
                     for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote (bvh_hit_ww)
-                        const bool more = FILT ? act && tv_node < FNODE_LEAF : act && !tv_have_leaf && tv_node != BVH_DONE;
+                        const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
                         n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
                         if (more) box_step();
                     }
                 }
                 if (few) break;                                   // (pending leaves wait for the next traversal pass)
                 DIAG_ADD(0);
-                n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(FILT ? act && (int32_t)tv_node >= (int32_t)FNODE_LEAF : act && tv_have_leaf));
-                if constexpr (FILT) {
-                    if (act && (int32_t)tv_node >= (int32_t)FNODE_LEAF) {
-                        const DBvhNode<T> lf = ld_node_at(P.bvh, tv_node & ~FNODE_LEAF);
-                        T t; uint32_t prim;
-                        if ((!tame || box_inside_tame(lf, r.o, inv, t_min, tv_closest)) &&           // aabb.rs:19-36 on the leaf's own box
-                            range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; F.c = up32(tv_closest); }
-                        tv_node = lf.skip;
-                    }
-                } else
+                n_leaf_steps++; n_leaf_lanes += (unsigned long long)__popcll(__ballot(act && tv_have_leaf));
                 if (act && tv_have_leaf) {
                     T t; uint32_t prim;
                     if (!near_first) {
@@ -1862,7 +1932,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                 }
                 DIAG_ADD(5);
             }
-            if (act && !tv_have_leaf && tv_node == BVH_DONE) {       // (filtered walk: a pending leaf is tv_node | FNODE_LEAF, never BVH_DONE)
+            if (act && !tv_have_leaf && tv_node == BVH_DONE) {
                 // ---- this BVH is done: its result joins the list search (hit.rs:62-69), the lane moves to the next object
                 if (tv_any) { closest = tv_closest; id.obj = my_oi; id.prim = tv_prim; any_hit = true; }
                 my_oi++;
@@ -1920,7 +1990,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
             const DObject ob = ld_obj(P.objects + oi);
             if (here) {
                 if (ob.geom_kind == G_BVH && (!(FEATS & F_MEDIUM) || ob.medium < 0)) {
-                    phase = PH_BVH; tv_node = ob.geom_first; tv_sp = 0; tv_closest = closest; tv_any = false; tv_best = 0; tv_have_leaf = false;
+                    phase = PH_BVH; tv_node = Filt<T, FEATS>::on ? state_of(P, ob.geom_first) : ob.geom_first; tv_sp = 0; tv_closest = closest; tv_any = false; tv_best = 0; tv_have_leaf = false;
                 } else {
                     object_hit<T, FEATS>(P, oi, ob, ray, TMin<T>::v(), rng, closest, id, any_hit, stack);
                     my_oi = oi + 1u;
@@ -1955,6 +2025,18 @@ __global__ void __launch_bounds__(Shape<FEATS>::THREADS, Shape<FEATS>::WAVES_PER
         // tree then no longer fits: bank conflicts are not what a step waits for.)
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         const u4* src = Filt<T, FEATS>::on ? (const u4*)P.bvh_f : (const u4*)P.bvh; u4* dst = (u4*)lds_raw;
+        if (Filt<T, FEATS>::on && all_in_lds(P)) {
+            // the whole tree is here: links become LDS addresses (a node state IS where its record lies: bvh_hit_filt); a leaf's info stays its id
+            const uint32_t base = lds_base();
+            for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) {
+                u4 w = src[i];
+                if (i & 1u) {                                     // second half of a DFNode: max.z-side bounds, skip, info
+                    if (w.z != ST_DONE) w.z = base + w.z * (uint32_t)sizeof(DFNode);
+                    if (!(w.w & FNODE_LEAF)) w.w = base + w.w * (uint32_t)sizeof(DFNode);
+                }
+                dst[i] = w;
+            }
+        } else
         for (uint32_t i = threadIdx.x; i < nodes_bytes / 16u; i += S::THREADS) dst[i] = src[i];
         __syncthreads();
     }
@@ -2064,10 +2146,24 @@ __global__ void aabb_kat_kernel(uint32_t n, const double* boxes, const double* r
     const bool exact = box_inside_exact(nd, o, inv, tlim[i * 2], tlim[i * 2 + 1]);
     const bool tame_ray = ray_is_tame(o, inv);
     const bool tame = box_inside_tame(nd, o, inv, tlim[i * 2], tlim[i * 2 + 1]);
-    out[i] = (exact ? 1 : 0) | (tame ? 2 : 0) | (tame_ray ? 4 : 0);
+    // the filtered walk's box step on this very box (outward-rounded to f32, M = its own largest |coordinate|: the tightest margin
+    // any node containing it can have): must pass wherever the exact test does, for rays inside the filter's ranges
+    DFNode fn; float m = 1.0f;
+    for (int k = 0; k < 3; k++) {
+        float lo = (float)nd.mn[k], hi = (float)nd.mx[k];
+        if ((double)lo > nd.mn[k]) lo = ::nextafterf(lo, -__builtin_inff());
+        if ((double)hi < nd.mx[k]) hi = ::nextafterf(hi, __builtin_inff());
+        fn.b[2 * k] = lo; fn.b[2 * k + 1] = hi;
+        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(lo), __builtin_fabsf(hi)));
+    }
+    fn.skip = fn.info = 0u;
+    const bool box_ok = m <= 0x1p40f;                  // (a NaN / infinite coordinate fails this: rt_flatten.cpp make_filter_nodes)
+    const BoxFilter F = make_filter(box_ok ? m : 0.0f, o, inv, tlim[i * 2], tlim[i * 2 + 1]);
+    out[i] = (exact ? 1 : 0) | (tame ? 2 : 0) | (tame_ray ? 4 : 0) | (F.ok ? 8 : 0) | (filter_pass(fn, F) ? 16 : 0);
 }
 }
-// out[i]: bit 0 = AABB::hit by the exact form, bit 1 = by the NaN-free form, bit 2 = the ray qualifies for the NaN-free form.
+// out[i]: bit 0 = AABB::hit by the exact form, bit 1 = by the NaN-free form, bit 2 = the ray qualifies for the NaN-free form,
+// bit 3 = ray and box are inside the f32 filter's ranges, bit 4 = the filter (rt_kernel.hip: filter_pass) lets the box through.
 // boxes: n x (min[3], max[3]); rays: n x (origin[3], direction[3]); tlim: n x (t_min, t_max).  Host pointers.
 extern "C" int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out) {
     if (n == 0) return 0;

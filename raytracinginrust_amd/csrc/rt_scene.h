@@ -54,7 +54,7 @@ struct Scene {
     std::vector<DPbr<double>> pbr;
     std::vector<uint8_t> image_bytes;
     int world = -1;
-    unsigned trav_hi = 40, trav_lo = 24, trav_leaf = 24;      // persistent-traversal schedule (rt_scene_set_traversal_schedule); measured best on the teapot room
+    unsigned trav_hi = 56, trav_lo = 16, trav_leaf = 32;      // persistent-traversal schedule (rt_scene_set_traversal_schedule); measured best on the teapot room (round 5, the filtered walk: profiles/r05_trav_schedule_sweep.log; 40 / 24 / 24 before)
     int bvh_builder = 0;      // 0: the reference's widest-axis object-median split (bvh.rs:18-73); 1: binned SAH (opt-in)
     std::vector<int> lights;
     std::string error;

@@ -746,6 +746,57 @@ def test_aabb_hit_on_the_device_against_the_oracle(pbe, obe):
     use = ((out & 4) != 0) & box_tame
     assert use.sum() > n // 2 and (~use).sum() > 100
     assert np.array_equal((out[use] >> 1) & 1, ref[use]), "the NaN-free form disagrees where it would be used"
+    # the filtered walk's f32 box step (rt_kernel.hip: filter_pass) is CONSERVATIVE: wherever it would be used it lets through
+    # every box the exact test passes (it may let through more: the exact test runs on the leaf's own box afterwards)
+    filt = use & ((out & 8) != 0)
+    assert filt.sum() > n // 2
+    assert not ((ref[filt] == 1) & ((out[filt] & 16) == 0)).any(), "the f32 filter culled a box AABB::hit passes"
+    plain = filt & (np.arange(n) % 4 != 0)                     # on ordinary rays it culls nearly everything the exact test culls
+    extra = ((ref[plain] == 0) & ((out[plain] & 16) != 0)).sum()
+    assert extra <= 0.001 * plain.sum(), f"the f32 filter passes {extra} boxes of {plain.sum()} that AABB::hit culls"
+
+
+def test_box_filter_is_conservative_on_grazing_rays(pbe):
+    """The f32 box step of the filtered walk must never cull a box whose exact AABB::hit passes (rt_kernel.hip: the proof above
+    make_filter).  Aimed at where a one-sided error would show: rays through points ON faces, edges and corners moved by 1e-15 ... 1e-3
+    of the box size, boxes far from the origin (coordinates up to 1e6: the f32 grid is coarse there), thin boxes (the reference's
+    0.0001-thick rect boxes), and [t_min, t_max] ending within a few ulps of the entry / exit distance.  Checked against the exact
+    form on the device, which test_aabb_hit_on_the_device_against_the_oracle ties to the oracle."""
+    import ctypes as C
+    rnd = np.random.default_rng(11)
+    n = 400000
+    scale = 10.0 ** rnd.uniform(-2, 6, (n, 1))
+    lo = rnd.uniform(-1, 1, (n, 3)) * scale
+    ext = rnd.uniform(0, 1, (n, 3)) * scale * 10.0 ** rnd.uniform(-4, 0, (n, 1))
+    thin = rnd.integers(0, 4, n) == 0
+    ext[thin, rnd.integers(0, 3, thin.sum())] = 0.0002
+    boxes = np.concatenate([lo, lo + ext], axis=1)
+    # a point on the box surface: each coordinate at min, max or inside; moved by a tiny relative offset
+    w = rnd.choice([0.0, 1.0, 0.5, 0.25], (n, 3), p=[0.35, 0.35, 0.2, 0.1])
+    tgt = lo + w * ext
+    tgt += rnd.choice([-1.0, 0.0, 1.0], (n, 3)) * 10.0 ** rnd.uniform(-15, -3, (n, 3)) * (np.abs(tgt) + ext)
+    o = tgt + rnd.normal(size=(n, 3)) * scale * 10.0 ** rnd.uniform(-3, 1, (n, 1))
+    d = tgt - o
+    d *= 10.0 ** rnd.uniform(-3, 3, (n, 1))                                   # |d| is not 1 in the reference either
+    t_hit = np.linalg.norm(tgt - o, axis=1) / np.maximum(np.linalg.norm(d, axis=1), 1e-300)
+    ulps = rnd.choice([-4, -1, 0, 1, 4, 1000], n)
+    tmax = np.where(rnd.integers(0, 2, n) == 0, np.inf, t_hit * (1.0 + ulps * 2.0 ** -52))
+    tmin = np.where(rnd.integers(0, 3, n) == 0, t_hit * (1.0 + rnd.choice([-4, -1, 0, 1, 4], n) * 2.0 ** -52), 1e-5)
+    tl = np.stack([tmin, tmax], axis=1)
+    rays = np.concatenate([o, d], axis=1)
+    out = np.zeros(n, dtype=np.int32)
+    lib = pbe.lib
+    lib.rt_debug_aabb_hit.restype = C.c_int
+    lib.rt_debug_aabb_hit.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    boxes, rays, tl = (np.ascontiguousarray(x, dtype=np.float64) for x in (boxes, rays, tl))
+    assert lib.rt_debug_aabb_hit(n, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, out.ctypes.data) == 0
+    use = ((out & 4) != 0) & ((out & 8) != 0)
+    assert use.sum() > 0.9 * n
+    exact = (out & 1) != 0
+    assert np.array_equal(exact[use], ((out >> 1) & 1)[use] != 0)
+    assert 0.2 * n < exact[use].sum() < 0.9 * n, "the cases should straddle the boundary"
+    culled = use & exact & ((out & 16) == 0)
+    assert not culled.any(), f"the f32 filter culled {int(culled.sum())} boxes AABB::hit passes, e.g. case {int(np.flatnonzero(culled)[0])}"
 
 
 @pytest.mark.parametrize("name", ["random", "final", "mesh0", "teapot"])

@@ -3,7 +3,7 @@ traversal passes, and inside the advance passes: shade (hit record + material), 
 path init, list walk up to the next BVH object."""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/ab/diag.so')
+os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/abx/diag.so')
 import torch
 from raytracinginrust_amd import _lib, render as R, scenes, workloads
 be = _lib.load()

@@ -3,7 +3,7 @@ without wrappers / BVH objects behind wrappers / all other objects, and how many
 Lock-step loop only; shares and counts, never a timing.   usage: RT_WORKLOADS=C3,C4 python tools/diag_objects.py [spp]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/ab/diagobj.so')
+os.environ['RT_AMD_LIB'] = os.path.join(ROOT, 'raytracinginrust_amd/csrc/abx/diagobj.so')
 import torch
 from raytracinginrust_amd import _lib, render as R, scenes, workloads
 be = _lib.load()

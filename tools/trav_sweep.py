@@ -14,7 +14,7 @@ def t(hi, lo, leaf):
     for _ in range(3):
         R.render(b, cam, bg, 960, 540, 64, 50); ms.append(R.last_kernel_ms(b))
     return min(ms)
-base = t(40, 24, 24); print(f'(40, 24, 24): {base:.3f} ms', flush=True)
+base = t(56, 16, 32); print(f'(56, 16, 32): {base:.3f} ms', flush=True)
 res = []
 for hi, lo, leaf in itertools.product((32, 40, 48, 56), (12, 16, 24, 32), (16, 24, 32)):
     if lo > hi: continue
