@@ -38,52 +38,12 @@
 #ifndef RT_TU
 #define RT_TU 0
 #endif
-#ifndef RT_BOX_STEPS             // box steps per box/leaf vote in the reference-order BVH loops (A/B in one process, % over one step per
-#define RT_BOX_STEPS 3           // vote: 2 steps random spheres +8.5, final scene +4.9; 3: +9.1 / +6.3; 4: +9.3 / +4.3)
-#endif
-#ifndef RT_BOX_STEPS_PERSIST     // ... and in the persistent loop (teapot room: 2 +0.5 %, 3 +1.9 %, 4 +6.6 %)
-#define RT_BOX_STEPS_PERSIST 4
-#endif
-#ifndef RT_SHARED_DIV3
-#define RT_SHARED_DIV3 (RT_TU == 2)
-#endif
 // Minimum resident waves per SIMD the register allocation is held to (512 VGPRs / waves, in steps of 8), per kernel family.
 // *Measured* (round 2, A/B in one process, with -disable-machine-licm): the lock-step BVH kernels are faster at 4 waves with a few
 // dozen spilled registers than at 3 without (random spheres +6.6 %, final scene +10 %); the persistent-traversal mesh kernel is not
-// (131 spills at 4 waves: teapot room -26 %).
-// shade_hit: Lambertian's two sampling arms and Metal share the instruction runs they have in common (round 4; samples bit-identical).
-// f64 kernels of the lean translation unit only: the f32 kernels draw one u32 per value, and in the BVH kernels the merged form moves
-// the register allocation for the worse (*measured* final scene -7 %, teapot room -3 %, random spheres -3.5 %; Cornell box +2.5 %,
-// +1.9 % without the first try of Metal's fuzz vector in the shared draws: profiles/r04_merged_arms_ab.log).
-#ifndef RT_MERGE_ARMS
-#define RT_MERGE_ARMS (RT_TU == 1)
-#endif
-// Lean kernels (list scenes): objects without wrappers test the path's own ray, `Translate(RotateY(..))` — the reference's instance idiom,
-// main.rs:300-309 — runs as straight-line code in the closest-hit search and in the hit record (anything else takes the generic
-// per-wrapper loops), constant colours come from the material record.  Samples bit-identical; *measured* Cornell box 30.9 -> 28.5 ms
-// per 800x800x256 on top of the merged arms (profiles/r04_lean_straight_ab.log).  0 = the generic loops only (A/B).
-#ifndef RT_LEAN_STRAIGHT
-#define RT_LEAN_STRAIGHT 1
-#endif
-// Launch parameters that only the camera / work-queue / flush code reads are fetched from the kernel-argument segment where they are
-// used instead of living in scalar registers through the bounce loop (cold_params below).  *Measured* (round 4, A/B in one process,
-// samples bit-identical): spilled scalar registers 86 -> 12 (lean), 106 -> 12 (final scene's kernel), 143 -> 34 (mesh); VGPRs 121 -> 104
-// (lean), scratch 132 -> 64 B (final scene), 132 -> 56 (random spheres), 68 -> 24 (mesh); Cornell box +2.2 %, final scene +5.6 %,
-// teapot room +4.7 %, random spheres +2.5 % (profiles/r04_cold_params_ab.log).  0 = every parameter by value (A/B).
-#ifndef RT_COLD_PARAMS
-#define RT_COLD_PARAMS 1
-#endif
-// Lock-step loop: the path's pixel is the accumulator's (one register), the live-lane and flush counters are wave-uniform (scalar
-// registers).  With it and RT_COLD_PARAMS the lean kernel fits 96 VGPRs with 2 spilled (27 without) = 5 waves per SIMD: *measured*
-// Cornell box 27.8 ms (4 waves) -> 26.8 (5 waves) -> 26.2 (5 waves, slim) per 800x800x256; neutral in the BVH kernels.
-#ifndef RT_SLIM_STATE
-#define RT_SLIM_STATE 1
-#endif
-#ifndef RT_MERGE_METAL_DRAWS
-#define RT_MERGE_METAL_DRAWS 1
-#endif
+// (131 spills at 4 waves: teapot room -26 %; round 5, filtered walk, 94 spills: -14 %); the lean kernel fits 5 since round 4.
 #ifndef RT_WAVES_LEAN
-#define RT_WAVES_LEAN 5      // (4 until round 4: see RT_SLIM_STATE)
+#define RT_WAVES_LEAN 5
 #endif
 #ifndef RT_WAVES_BVH
 #define RT_WAVES_BVH 4
@@ -94,19 +54,18 @@
 #ifndef RT_WAVES_PBR
 #define RT_WAVES_PBR 3
 #endif
-#ifndef RT_WW_NUM
-#define RT_WW_NUM 5u      // (3/8 until the filtered walk made box steps cheap: final scene +2 ... +5 % at 5/8, profiles/r05_ww_vote_ab.log)
-#define RT_WW_DEN 8u
-#endif
-#ifndef RT_SPECULATE
-#define RT_SPECULATE 0
-#endif
-#ifndef RT_SPEC_NUM
-#define RT_SPEC_NUM 5u
-#define RT_SPEC_DEN 8u
-#endif
 
 namespace rt {
+
+// Settled by A/B measurements (docs/history.md names the logs; tools/mkvariant.sh patches a copy of this file for a re-measurement):
+static constexpr int BOX_STEPS = 3;             // box steps per box-or-leaf vote, lock-step BVH loops (round 5, filtered walk: 2 -1 %, 4 +1 %, 6 +2 %)
+static constexpr int BOX_STEPS_PERSIST = 4;     // ... persistent loop (round 5: 3 -2 %, 6 +1.5 %, 8 +2 %)
+static constexpr uint32_t WW_NUM = 5u, WW_DEN = 8u;       // leaf step once 5/8 of the lanes still in a walk hold a pending leaf (3/8 until round 5)
+static constexpr uint32_t SPEC_NUM = 5u, SPEC_DEN = 8u;   // ... in the walk-ahead form (one-BVH worlds)
+// The kernels are two translation units (RT_TU, above) so that these two code-generation choices can differ between them:
+static constexpr bool SHARED_DIV3 = RT_TU == 2;  // shared-denominator Vec3 division: +3.8 % teapot room, +1.7 % final scene; -1.2 % Cornell box
+static constexpr bool MERGE_ARMS = RT_TU == 1;   // shade_hit: Lambertian's two sampling arms and Metal share their common instruction runs (round 4,
+                                                 // samples bit-identical): Cornell box +2.5 %; in the BVH kernels -3 ... -7 % (register allocation)
 
 // ------------------------------------------------------------------ small vector algebra (src/vec.rs)
 template <typename T> struct V3 { T x, y, z; };
@@ -124,9 +83,7 @@ template <typename T> DEV V3<T> operator*(T s, V3<T> a) { return mk<T>(s * a.x, 
 // finishes with its own numerator: the same instructions on the same values, bit for bit the three separate divisions.
 // Otherwise (checked) the three plain divisions run.
 DEV V3<double> operator/(V3<double> a, double d) {
-#if !RT_SHARED_DIV3
-    return mk<double>(a.x / d, a.y / d, a.z / d);
-#else
+    if (!SHARED_DIV3) return mk<double>(a.x / d, a.y / d, a.z / d);
     bool fx, fy, fz, unused;
     const double d0 = __builtin_amdgcn_div_scale(a.x, d, false, &unused);
     const double d1 = __builtin_amdgcn_div_scale(a.y, d, false, &unused);
@@ -147,7 +104,6 @@ DEV V3<double> operator/(V3<double> a, double d) {
         return o;
     }
     return mk<double>(a.x / d, a.y / d, a.z / d);
-#endif
 }
 DEV V3<float> operator/(V3<float> a, float s) { return mk<float>(a.x / s, a.y / s, a.z / s); }
 template <typename T> DEV T dot(V3<T> a, V3<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }                  // vec.rs:38-40
@@ -169,7 +125,6 @@ template <typename T> DEV V3<T> cl3(const T* p) { return mk<T>(cl(p), cl(p + 1),
 // Launch parameters that only the camera / work-queue code reads (camera, frame size, tiling, chunking, seed: ~60 scalar registers):
 // read from the kernel-argument segment where they are used, through a laundered pointer, instead of living in — and being spilled
 // from — scalar registers through the whole bounce loop.  (The kernel's only argument is the KParams block, at offset 0.)
-#if RT_COLD_PARAMS
 #define COLD_K const KParams<T>* K = cold_params<T>()
 #define PK(f) cl(&K->f)
 template <typename T> DEV const KParams<T>* cold_params() {
@@ -177,10 +132,6 @@ template <typename T> DEV const KParams<T>* cold_params() {
     asm volatile("" : "+s"(k));
     return k;
 }
-#else
-#define COLD_K const KParams<T>* K = &P
-#define PK(f) (K->f)
-#endif
 // Whole-record fetch of a 16-byte-aligned POD record as 16-byte (then 8 / 4-byte) pieces through the constant address space.
 template <typename R> DEV R ld_record(const R* p) {
     static_assert(alignof(R) >= 16 && sizeof(R) % 4 == 0, "record must be 16-byte aligned");
@@ -468,13 +419,18 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
 }
 
 // ------------------------------------------------------------------ the filtered walk (f64 kernels, reference traversal order)
-// BVH::hit (bvh.rs:77-91) tests a leaf's primitives iff the leaf's OWN box passes AABB::hit with the closest hit at that moment: every
-// ancestor's box contains the leaf's, so (monotonic rounding, see bvh_hit_spec below) it passes whenever the leaf's does — the recursion
-// is an ordered scan of the leaves, and the inner boxes only decide how much of that scan can be skipped.  Nothing about a SKIPPED
-// subtree reaches the result.  So the box steps need not run the reference's arithmetic: any test that never fails where the exact
-// test of a leaf below would pass visits the same leaves with the same closest hits, and the exact f64 test (aabb.rs:19-36) is run
-// once, on the leaf's own box, in the leaf step.  The box steps here are that: f32 slab tests on outward-rounded boxes with an error
-// margin, ~15 f32 instructions and two 16-byte LDS reads per node instead of ~45 f64 / select instructions and four reads.
+// BVH::hit (bvh.rs:77-91) tests a leaf's primitives iff the leaf's OWN box passes AABB::hit with the closest hit at that moment:
+//   (=>) the recursion tests the leaf's box itself;  (<=) a parent's bounds are the min / max of its children's (aabb.rs:40-51), and
+//   subtraction, multiplication by 1/d and min / max are monotonic in floating point, so a child's slab interval lies inside every
+//   ancestor's — exactly, not approximately; and a box test made earlier saw a closest hit that was no smaller.  So when the leaf's box
+//   passes with the present closest hit, every ancestor passed on the way down: the recursion is standing at this leaf with this t_max.
+// The recursion is therefore an ORDERED SCAN OF THE LEAVES — own box, then primitives, the closest hit running — and the inner boxes only
+// decide how much of the scan can be skipped; nothing about a skipped subtree reaches the result.  (Round 3 shipped a first use of this:
+// speculative box steps past an untested leaf; round 5 takes it to its end.)  So the box steps need not run the reference's arithmetic:
+// any test that never fails where the exact test of a leaf below would pass visits the same leaves with the same closest hits, and the
+// exact f64 test (aabb.rs:19-36) is run once, on the leaf's own box, in the leaf step.  The box steps here are that: f32 slab tests on
+// outward-rounded boxes with an error margin, 18 f32 instructions and two 16-byte LDS reads per node instead of ~45 f64 / select
+// instructions and four reads.  The same freedom lets the flattener take near-duplicate inner nodes out (rt_flatten.cpp: contraction).
 //
 // CONSERVATIVE, proof.  Ray (o, inv = 1/d as the kernel computes it, both f64), a leaf box B, a node X whose f64 box contains B, X32 its
 // outward-rounded f32 box (contains B too).  For axis j let N_j(.) / F_j(.) be the REAL near / far slab values min / max((mn_j - o_j) inv_j,
@@ -514,13 +470,8 @@ DEV bool filter_pass(const DFNode& nd, const BoxFilter& F) {
     const float a0 = __builtin_fmaf(nd.b[0], F.ix, F.ax), b0 = __builtin_fmaf(nd.b[1], F.ix, F.bx);
     const float a1 = __builtin_fmaf(nd.b[2], F.iy, F.ay), b1 = __builtin_fmaf(nd.b[3], F.iy, F.by);
     const float a2 = __builtin_fmaf(nd.b[4], F.iz, F.az), b2 = __builtin_fmaf(nd.b[5], F.iz, F.bz);
-#ifdef RT_EXP_BUILTIN_MM
-    const float t_in = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, b0), __builtin_fminf(a1, b1)), __builtin_fminf(a2, b2)), F.tmin);
-    const float t_o = __builtin_fminf(__builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(a1, b1)), __builtin_fmaxf(a2, b2)), F.c);
-#else
     const float t_in = max_nn(max3_nn(min_nn(a0, b0), min_nn(a1, b1), min_nn(a2, b2)), F.tmin);
     const float t_o = min_nn(min3_nn(max_nn(a0, b0), max_nn(a1, b1), max_nn(a2, b2)), F.c);
-#endif
     return !(t_o < t_in);
 }
 // Where a walk stands is one word per lane, a STATE: a node (box step next) | a leaf's id with FNODE_LEAF set (its box passed the
@@ -578,7 +529,7 @@ DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double
             const bool want_box = st_walking(node);
             const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(SPEC ? p1 != ST_DONE : st_pending(node)));
             const uint32_t n_act = SPEC ? (uint32_t)__popcll(__ballot(node != ST_DONE || p1 != ST_DONE)) : n_box + n_leaf;
-            if (n_box == 0u || n_leaf * (SPEC ? RT_SPEC_DEN : RT_WW_DEN) >= n_act * (SPEC ? RT_SPEC_NUM : RT_WW_NUM)) break;
+            if (n_box == 0u || n_leaf * (SPEC ? SPEC_DEN : WW_DEN) >= n_act * (SPEC ? SPEC_NUM : WW_NUM)) break;
             auto box_step = [&]() {
                 const DFNode nd = fetch_fnode<ALL>(P, node);
                 const bool pass = filter_pass(nd, F);
@@ -588,7 +539,7 @@ DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double
             };
             if (want_box) box_step();
 #pragma unroll
-            for (int k = 1; k < RT_BOX_STEPS; k++) if (st_walking(node)) box_step();
+            for (int k = 1; k < BOX_STEPS; k++) if (st_walking(node)) box_step();
         }
     };
     for (;;) {
@@ -598,11 +549,7 @@ DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double
         if (leaf != ST_DONE) {
             const DBvhNode<double> lf = ld_node_at(P.bvh, leaf);
             double t; uint32_t prim;
-#ifdef RT_EXP_NO_LEAF_BOX
-            if (
-#else
             if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
-#endif
                 range_hit<double, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
             if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
             else node = fnode_skip(P, leaf);
@@ -628,7 +575,7 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     // and t_max updates is exactly the recursion's (bbox, left, right): a lane that reaches a leaf keeps it pending and waits.
     // *Measured* against "every lane waits until all hold a leaf": final scene +8 %, random spheres +15 %; against one node (box and
     // leaf) per iteration on the teapot mesh: +8 %.
-    // Box steps go on until the lanes holding a leaf are at least RT_WW_NUM/RT_WW_DEN (3/8: the best of 1/8 .. 1) of the lanes still
+    // Box steps go on until the lanes holding a leaf are at least WW_NUM/WW_DEN (3/8: the best of 1/8 .. 1) of the lanes still
     // walking, or nobody can step; then the pending leaves are tested together.
     uint32_t leaf_a = 0, leaf_b = 0, leaf_node = 0;
     bool have_leaf = false;
@@ -638,7 +585,7 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
         for (;;) {
             const bool want_box = node != DONE && !have_leaf;
             const uint32_t n_box = (uint32_t)__popcll(__ballot(want_box)), n_leaf = (uint32_t)__popcll(__ballot(have_leaf));
-            if (n_box == 0u || n_leaf * RT_WW_DEN >= (n_box + n_leaf) * RT_WW_NUM) break;
+            if (n_box == 0u || n_leaf * WW_DEN >= (n_box + n_leaf) * WW_NUM) break;
             auto box_step = [&]() {
                 const DBvhNode<T> nd = fetch_node(P, node);
                 const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, closest) : box_inside_exact(nd, ray.o, inv, t_min, closest);
@@ -662,7 +609,7 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
             // further box steps under the same vote (the vote is ~30 scalar instructions and two ballots: *measured* with two steps
             // per vote random spheres +8 %, final scene +4 %); a lane that reached a leaf or the end sits them out
 #pragma unroll
-            for (int k = 1; k < RT_BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
+            for (int k = 1; k < BOX_STEPS; k++) if (node != DONE && !have_leaf) box_step();
         }
         if (have_leaf) {
             T t; uint32_t prim;
@@ -676,64 +623,9 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     return any;
 }
 
-// The same search with SPECULATIVE box steps (reference order, tame rays): a lane that has reached a leaf does not wait for the leaf step
-// — it walks on along the leaf's skip link with its closest hit as it is, and waits only once it holds a second leaf.  The leaf step
-// tests one pending leaf per lane; a leaf that was reached past an untested one is first re-tested against its own box with the closest
-// hit as it is NOW, and dropped if that fails.  Same result as BVH::hit (bvh.rs:77-91), by containment: a child's box lies inside its
-// parent's (the parent's bounds are the min / max of the children's, aabb.rs:40-51), subtraction, multiplication by 1/d and min / max are
-// monotonic, so a child's slab interval lies inside every ancestor's — exactly, in floating point.  Hence (1) if the leaf's box passes
-// with the current closest hit, every ancestor on the way to it passes too: the recursion would have reached the leaf and tested it with
-// this very t_max; (2) if it fails, the recursion would have failed at the leaf's box or earlier and never tested the leaf; (3) box
-// tests made with the stale (larger) closest hit can only pass where the recursion's would fail, never the reverse, so no leaf the
-// recursion tests is missed, and the extra nodes walked below a box the recursion would have culled all fail their own re-test.
-// Where it pays (*measured*, round 3; leaf step once 3/8 ... 8/8 of the active lanes hold a leaf): random spheres — every lane enters the
-// tree — +1.6 / +2.1 / +2.6 (5/8) / +2.3 / -5 %; final scene -3 %, teapot room in lock-step -3 % (few lanes enter: the waiting it removes is
-// a fifth of the box steps' lane-slots and half of what it walks instead is wasted).  So it has its own instantiation (F_SPEC), chosen
-// by the host for scenes whose world is one BVH; -DRT_SPECULATE=1 turns it on in every lock-step BVH kernel (measurement builds).
-template <typename T, uint32_t FEATS>
-DEV bool bvh_hit_spec(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
-    const V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
-    T closest = t_max;
-    bool any = false;
-    const uint32_t NONE = 0xFFFFFFFFu;
-    uint32_t node = root, p1 = NONE, p2 = NONE;        // where the walk stands; the pending leaves (node ids), oldest first
-    bool spec1 = false;                                // p1 was reached past an untested leaf: its box is re-tested before its primitives
-    const bool tame = P.bvh_tame != 0u && __ballot(!ray_is_tame(ray.o, inv)) == 0ull;   // wave-uniform; untamed rays (NaNs possible) do not speculate
-    for (;;) {
-        for (;;) {
-            const bool can_box = node != NONE && (tame ? p2 == NONE : p1 == NONE);
-            const uint32_t n_box = (uint32_t)__popcll(__ballot(can_box)), n_leaf = (uint32_t)__popcll(__ballot(p1 != NONE)),
-                           n_act = (uint32_t)__popcll(__ballot(node != NONE || p1 != NONE));
-            if (n_box == 0u || n_leaf * RT_SPEC_DEN >= n_act * RT_SPEC_NUM) break;
-            auto box_step = [&]() {
-                const DBvhNode<T> nd = fetch_node(P, node);
-                const bool inside = tame ? box_inside_tame(nd, ray.o, inv, t_min, closest) : box_inside_exact(nd, ray.o, inv, t_min, closest);
-                const bool leaf = (nd.a & BVH_LEAF) != 0u;
-                if (inside && leaf) { if (p1 == NONE) p1 = node; else p2 = node; }
-                node = (inside && !leaf) ? nd.c : nd.skip;
-            };
-            if (can_box) box_step();
-#pragma unroll
-            for (int k = 1; k < RT_BOX_STEPS; k++) if (node != NONE && (tame ? p2 == NONE : p1 == NONE)) box_step();
-        }
-        if (p1 != NONE) {
-            const DBvhNode<T> lf = fetch_node(P, p1);
-            bool go = true;
-            if (spec1) go = box_inside_tame(lf, ray.o, inv, t_min, closest);           // (speculation only happens on tame rays)
-            T t; uint32_t prim;
-            if (go && range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; }
-            p1 = p2; spec1 = p2 != NONE; p2 = NONE;
-        }
-        if (__ballot(node != NONE || p1 != NONE) == 0ull) break;
-    }
-    t_out = closest;
-    return any;
-}
-
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
-    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<FEATS, (RT_SPECULATE || (FEATS & F_SPEC)) != 0u>(P, root, ray, t_min, t_max, t_out, prim_out);
-    if ((RT_SPECULATE || (FEATS & F_SPEC)) && !(FEATS & F_NEAR_FIRST)) return bvh_hit_spec<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out);
+    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<FEATS, (FEATS & F_SPEC) != 0u>(P, root, ray, t_min, t_max, t_out, prim_out);
     return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack);
 }
 
@@ -769,7 +661,6 @@ DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_
 // running (closest, id).  ConstantMedium objects draw from the path's RNG (medium.rs:44).
 template <typename T, uint32_t FEATS>
 DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack) {
-#if RT_LEAN_STRAIGHT
     if (FEATS == 0u && ob.n_ops == 2u) {        // Translate(RotateY(..)), the reference's instance idiom (main.rs:300-309): straight-line code
         const DOp<T> o0 = ld_op(P.ops + ob.first_op), o1 = ld_op(P.ops + ob.first_op + 1u);
         if (o0.kind == OP_TRANSLATE && o1.kind == OP_ROTATE && o1.axis == 1u) {
@@ -788,7 +679,6 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
         if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
         return;
     }
-#endif
     RayT<T> r = ray;
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
@@ -879,7 +769,6 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         return;
     }
     RayT<T> r = ray;
-#if RT_LEAN_STRAIGHT
     bool fused = false;
     DOp<T> f0, f1;
     if (FEATS == 0u && ob.n_ops == 2u) {
@@ -891,7 +780,6 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         r.o.x = f1.y * q.x - f1.x * q.z; r.o.y = q.y; r.o.z = f1.x * q.x + f1.y * q.z;
         r.d.x = f1.y * ray.d.x - f1.x * ray.d.z; r.d.z = f1.x * ray.d.x + f1.y * ray.d.z;
     } else
-#endif
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     const uint32_t kind = id.prim >> 28, idx = id.prim & 0x0FFFFFFFu;
     if (kind == G_RECT) {                                                             // rect.rs:61-79
@@ -932,7 +820,6 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         rec.mat = tr.mat;
     }
     // unwind the wrapper chain innermost -> outermost
-#if RT_LEAN_STRAIGHT
     if (fused) {
         rot_back(1u, f1.x, f1.y, rec.p);                                              // rotate.rs:90-104
         V3<T> nw = rec.n;
@@ -941,7 +828,6 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
         rec.p = rec.p + mk<T>(f0.x, f0.y, f0.z);                                      // translate.rs:26
         return;
     }
-#endif
     for (int k = (int)ob.n_ops - 1; k >= 0; k--) {
         const DOp<T> op = ld_op(P.ops + ob.first_op + (uint32_t)k);
         if (op.kind == OP_TRANSLATE) {
@@ -1272,13 +1158,8 @@ DEV void flush_acc(const KParams<T>& P, bool need, uint32_t acc_px, const A& acc
         if (lane == leader) {
             double* o = out + (size_t)px * 3u;        // hardware f64 atomics: a pixel's samples may be split over several waves
             unsafeAtomicAdd(o + 0, s0); unsafeAtomicAdd(o + 1, s1); unsafeAtomicAdd(o + 2, s2);
-#if !RT_SLIM_STATE
-            n_flush++;
-#endif
         }
-#if RT_SLIM_STATE
         n_flush++;                                    // wave-uniform (a scalar register)
-#endif
         need = need && !mine;
         m = __ballot(need);
     }
@@ -1428,7 +1309,7 @@ DEV bool take_new_paths(const KParams<T>& P, WaveWork& w, uint32_t lane, T* q_re
 // hold — rt_flatten.cpp copies a constant texture's colour there — instead of gathering the texture record behind it (*measured* +1.4 %
 // on the Cornell box; no gain in the BVH kernels, which keep the texture walk).
 template <typename T, uint32_t FEATS> DEV V3<T> const_or_tex(const KParams<T>& P, const DMaterial<T>& mt, const Rec<T>& rec) {
-    if (FEATS == 0u && RT_LEAN_STRAIGHT) return ld3(mt.albedo);
+    if (FEATS == 0u) return ld3(mt.albedo);
     return tex_eval<T, FEATS>(P, mt.tex, rec.u, rec.v, rec.p);
 }
 // U01 / R(a,b) of rt_rng.h from a u64 that was drawn earlier (shade_hit draws for several arms at once)
@@ -1448,7 +1329,7 @@ DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& 
     // values — per lane the operations and the draw order are exactly those of the separate arms below (bit-identical samples):
     // (1) the first normalisation (onb.rs:10 / vec.rs:112-114 + mat.rs:285), (2) the next two u64 draws (pdf.rs:10-11 /
     // rect.rs:104-105 / the first try of vec.rs:80); the cosine pdf is computed once for the scenes with and without lights.
-    constexpr bool MERGE = RT_MERGE_ARMS && sizeof(T) == 8u;               // (the f32 kernels draw one u32 per value)
+    constexpr bool MERGE = MERGE_ARMS && sizeof(T) == 8u;               // (the f32 kernels draw one u32 per value)
     const bool lam = mt.kind == M_LAMBERTIAN, met = mt.kind == M_METAL;
     if (MERGE && (lam || met)) { if constexpr (MERGE) {
         V3<T> unit0 = rec.n;
@@ -1468,11 +1349,7 @@ DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& 
                 L = ld_light(P.lights + rng_index(rng, P.n_lights));        // hit.rs:94-96
             }
         }
-#if RT_MERGE_METAL_DRAWS
         const bool two = !to_light || L.kind == L_RECT;
-#else
-        const bool two = lam && (!to_light || L.kind == L_RECT);
-#endif
         uint64_t b1 = 0, b2 = 0;
         if (two) { b1 = rng_u64(rng); b2 = rng_u64(rng); }
         if (lam) {
@@ -1508,13 +1385,9 @@ DEV void shade_hit(const KParams<T>& P, const Rec<T>& rec, RayT<T>& ray, V3<T>& 
             beta = (beta * (attenuation * sc)) / pdf_value;                 // main.rs:97 (emitted is the literal zero here)
             ray.o = rec.p; ray.d = dir;                                     // time unchanged
         } else {                                                            // mat.rs:280-293
-#if RT_MERGE_METAL_DRAWS
             V3<T> fz;                                                       // random_in_unit_sphere, vec.rs:78-85: the first try's a and b are drawn above
             fz.x = rng_range_of(b1, T(-1.0), T(1.0)); fz.y = rng_range_of(b2, T(-1.0), T(1.0)); fz.z = rng_range(rng, T(-1.0), T(1.0));
             while (!(dot(fz, fz) < T(1.0))) { T a = rng_range(rng, T(-1.0), T(1.0)), b = rng_range(rng, T(-1.0), T(1.0)), c = rng_range(rng, T(-1.0), T(1.0)); fz = mk<T>(a, b, c); }
-#else
-            V3<T> fz = random_in_unit_sphere<T>(rng);
-#endif
             V3<T> sd = unit0 + mt.param * fz;
             if (dot(sd, rec.n) > T(0)) { beta = ld3(mt.albedo) * beta; ray.o = rec.p; ray.d = sd; }   // main.rs:89-91
             else done = true;                                               // None -> emitted = 0, main.rs:108-110
@@ -1633,11 +1506,7 @@ DEV unsigned long long* stats_row(unsigned long long* stats) {     // one of the
 DEV void write_stats(unsigned long long* stats, uint32_t lane, uint32_t n_nonfinite, unsigned long long n_iters, unsigned long long n_active, uint32_t n_flush) {
     if (!stats) return;
     if (n_nonfinite) atomicAdd(&stats[0], (unsigned long long)n_nonfinite);
-#if RT_SLIM_STATE
     if (lane == 0 && n_flush) atomicAdd(&stats[11], (unsigned long long)n_flush);
-#else
-    if (n_flush) atomicAdd(&stats[11], (unsigned long long)n_flush);
-#endif
     if (lane == 0) { atomicAdd(&stats[1], n_iters); atomicAdd(&stats[2], n_active); }      // (both wave-uniform: kept in scalar registers)
 }
 
@@ -1652,12 +1521,8 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     bool alive = false;
     RayT<T> ray; ray.o = mk<T>(T(0), T(0), T(0)); ray.d = ray.o; ray.tm = T(0);
     V3<T> beta = mk<T>(T(0), T(0), T(0));
-#if RT_SLIM_STATE
     uint32_t depth_left = 0, path_s = 0;                 // (the path's pixel is the accumulator's: acc_px)
 #define path_px acc_px
-#else
-    uint32_t depth_left = 0, path_px = 0, path_s = 0;
-#endif
     Rng rng; rng.s0 = rng.s1 = rng.s2 = rng.s3 = 0;
     // per-lane accumulator for one local pixel
     uint32_t acc_px = NONE_PX;
@@ -1680,20 +1545,13 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
 
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
-#if !RT_SLIM_STATE
-            path_px = new_px;
-#endif
             beta = mk<T>(T(1.0), T(1.0), T(1.0));
             depth_left = P.max_depth;
             alive = true;
         }
 
         n_iters++;
-#if RT_SLIM_STATE
         n_active += (unsigned long long)__popcll(__ballot(alive));
-#else
-        if (alive) n_active++;
-#endif
         DIAG_ADD(1);
 
         // ---- one level of ray_color (main.rs:41-120) for every live lane
@@ -1736,10 +1594,6 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
     flush_acc(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
     unsigned long long* st; { COLD_K; st = stats_row(PK(stats)); }
     unsigned long long live = n_active;
-#if !RT_SLIM_STATE
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) live += __shfl_xor(live, off, 64);
-#endif
     write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
 #ifdef RT_DIAG
     if (st && lane == 0) for (int k = 0; k < 6; k++) atomicAdd(&st[3 + k], dg_sum[k]);
@@ -1831,7 +1685,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                         auto box_step = [&]() { const DFNode nd = fetch_fnode<ALL>(P, tv_node); tv_node = filter_pass(nd, F) ? nd.info : nd.skip; };
                         if (want_box) box_step();
 #pragma unroll
-                        for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote
+                        for (int k = 1; k < BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote
                             const bool more = act && st_walking(tv_node);
                             n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
                             if (more) box_step();
@@ -1851,11 +1705,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                         const uint32_t leaf = tv_node & ~FNODE_LEAF;
                         const DBvhNode<T> lf = ld_node_at(P.bvh, leaf);
                         T t; uint32_t prim;
-#ifdef RT_EXP_NO_LEAF_BOX
-                        if (
-#else
                         if ((!tame || box_inside_tame(lf, r.o, inv, t_min, tv_closest)) &&           // aabb.rs:19-36 on the leaf's own box
-#endif
                             range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; F.c = up32(tv_closest); }
                         tv_node = fnode_skip(P, leaf);
                     }
@@ -1911,7 +1761,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                     };
                     if (want_box) box_step();
 #pragma unroll
-                    for (int k = 1; k < RT_BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote (bvh_hit_ww)
+                    for (int k = 1; k < BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote (bvh_hit_ww)
                         const bool more = act && !tv_have_leaf && tv_node != BVH_DONE;
                         n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
                         if (more) box_step();

@@ -756,6 +756,47 @@ def test_aabb_hit_on_the_device_against_the_oracle(pbe, obe):
     assert extra <= 0.001 * plain.sum(), f"the f32 filter passes {extra} boxes of {plain.sum()} that AABB::hit culls"
 
 
+def _big_mesh_room(be, n_tris):
+    rs = np.random.RandomState(5)
+    b = SceneBuilder(be)
+    white = b.Lambertian(b.ConstantTexture((0.73, 0.73, 0.73)))
+    light = b.DiffuseLight(b.ConstantTexture((12.0, 12.0, 12.0)))
+    world = b.HittableList()
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, 150.0, 400.0, 150.0, 400.0, 554.0, light))
+    world.push(lamp)
+    world.push(b.AARect(Plane.XZ, 0.0, 555.0, 0.0, 555.0, 0.0, white))
+    world.push(b.AARect(Plane.XY, 0.0, 555.0, 0.0, 555.0, 555.0, white))
+    tris = []
+    for _ in range(n_tris):
+        p0 = np.array([278.0, 200.0, 250.0]) + rs.uniform(-150, 150, 3)
+        tris.append(b.Triangle([tuple(p0), tuple(p0 + rs.uniform(-12, 12, 3)), tuple(p0 + rs.uniform(-12, 12, 3))], white))
+    world.push(b.BVH(tris, 0.0, 1.0))
+    b.set_scene(world, [lamp])
+    cam = Camera((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return b, cam, (0.02, 0.02, 0.03)
+
+
+def test_tree_larger_than_the_lds(pbe, obe, orc_mod, monkeypatch):
+    """A tree of 9999 nodes does not fit the CU's LDS even as 32-byte filter nodes: the top levels are staged, the rest comes from
+    memory, node states are ids instead of LDS addresses (rt_kernel.hip: fetch_fnode<false>).  Both loop shapes, the cache on / off:
+    every sample bit-identical, and equal to the oracle's."""
+    b, cam, bg = _big_mesh_room(pbe, 5000)
+    W, H, spp, depth = 48, 36, 4, 12
+    _, pers = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_PERSISTENT_BVH, want_samples=True)
+    info = R.last_launch_info(b)
+    assert info["bvh_nodes"] == 9999 and 0 < info["bvh_nodes_in_lds"] < info["bvh_nodes"]
+    _, lock = R.render(b, cam, bg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
+    assert np.array_equal(pers.view(np.uint64), lock.view(np.uint64))
+    monkeypatch.setenv("RT_NODE_CACHE_MAX", "0")
+    _, none = R.render(b, cam, bg, W, H, spp, depth, want_samples=True)
+    monkeypatch.delenv("RT_NODE_CACHE_MAX")
+    assert np.array_equal(pers.view(np.uint64), none.view(np.uint64))
+    ob, ocam, obg = _big_mesh_room(obe, 5000)
+    _, ref = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True)
+    n_div, _, _ = _compare_samples(pers, ref)
+    assert n_div <= MAX_DIVERGED
+
+
 def test_box_filter_is_conservative_on_grazing_rays(pbe):
     """The f32 box step of the filtered walk must never cull a box whose exact AABB::hit passes (rt_kernel.hip: the proof above
     make_filter).  Aimed at where a one-sided error would show: rays through points ON faces, edges and corners moved by 1e-15 ... 1e-3
