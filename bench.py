@@ -141,6 +141,11 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
             "traffic_source": None, "hbm_measured_GBps": None, "hbm_measured_frac": None,
             "ops_per_sample": ops, "flops_per_sample_unweighted": workloads.flops(per_kind),
             "achieved_unweighted_TFLOPs": workloads.flops(per_kind) * local_samples / (k_ms * 1e-3) / 1e12,
+            # the same kernel time priced WITHOUT issue weights, against the chip's f64 vector specification (78.6 TFLOP/s counts an FMA
+            # as two flops; this path has none): every +, -, x, /, sqrt and libm call counts once.  `frac` above prices the compiler's
+            # 11-instruction IEEE divide, the square root and the libm calls at what they cost in issue slots.
+            "frac_unweighted": workloads.flops(per_kind) * local_samples / (k_ms * 1e-3) / 78.6e12, "peak_unweighted_TFLOPs": 78.6,
+            "divide_share_of_weighted_ops": workloads.VALU_OP_WEIGHTS["div"] * per_kind.get("div", 0.0) / ops,
             "ops_per_sample_source": "raytracinginrust_amd/workloads.py F64_OPS_PER_SAMPLE x VALU_OP_WEIGHTS (the reference's f64 operations by kind, counted by "
                                      "the op-counting build of the CPU oracle on this workload's own grid; tests/sweeps/measure_ops_per_sample.py)",
             "peak_source": "256 CUs x 4 SIMDs x 16 f64 lanes/clk x 2.4 GHz = 39.3e12 lane-operations/s (78.6 TFLOP/s spec counts an FMA as 2; the path has none); "
@@ -293,6 +298,27 @@ def main():
             R.set_bvh_builder(b, R.RT_BVH_SAH)
         return b, cam, bg
 
+    def check_rows(b, cam, bg, w, frame_rows):
+        """Self-validation of a frame, outside every timed region: rows H/2 and H/2 + 1 of the SAME frame rendered again on this device
+        alone — tile = one image row, world = H, rank = the row: one launch per row, no sharding, no gather, no un-permute — against
+        the rows the step produced (`frame_rows`: 2 x W x 3, host).  Same paths (the RNG is keyed by pixel and sample), so the sums
+        agree to summation-order rounding; a wrong un-permute, a rank that rendered nothing or a stale buffer does not."""
+        r0 = w.H // 2
+        ref = []
+        for row in (r0, r0 + 1):
+            tr = D.TileRenderer(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags, tile_px=w.W, rank=row, world=w.H)
+            ref.append(tr.render_local().clone())
+            del tr
+        torch.cuda.synchronize()
+        ref = torch.stack(ref, 0).reshape(2, w.W, 3).cpu().numpy()
+        got = np.asarray(frame_rows, dtype=np.float64).reshape(2, w.W, 3)
+        fin = np.isfinite(ref) & np.isfinite(got)
+        tol = 1e-12 * (w.spp + np.abs(np.where(fin, ref, 0.0)))
+        diff = np.abs(np.where(fin, got, 0.0) - np.where(fin, ref, 0.0))
+        ok = bool(np.array_equal(np.isfinite(ref), np.isfinite(got)) and (diff <= tol).all() and float(np.abs(np.where(fin, got, 0.0)).sum()) > 0.0)
+        return {"rows": [r0, r0 + 1], "max_abs_diff": float(diff.max()), "tolerance": "1e-12 * (spp + |x|) per channel sum",
+                "reference": "the same rows rendered by one launch each on rank 0's device alone (tile = row, no gather, no un-permute)", "ok": ok}
+
     def run_procs(w, steps, warmup, warm_spp=None, pipeline=1):
         """One process per GPU (or the one GPU): time `steps` frames of workload `w` (after `warmup` untimed ones; `warm_spp` renders the
         warm-up frames at a reduced sample count through the same kernel and scene).  Returns what rank 0 needs for its line."""
@@ -320,13 +346,22 @@ def main():
         assert k_launches == steps
         res = {"w": w, "elapsed": elapsed, "steps": steps, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
                "pipeline": tr.pipeline, "multi_ms": None, "stats_scope": "rank 0's share" if world > 1 else "frame"}
-        if rank == 0:
-            assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
-            res["mean_radiance"] = float(torch.nan_to_num(frame).mean().item()) / w.spp
-        n_px = w.W * w.H                     # real (unpadded) pixels rank 0's launch owns
+        n_px = w.W * w.H                     # real (unpadded) pixels this rank's launch owns
         local_px = sum(max(0, min(n_px, (t + 1) * args.tile_px) - t * args.tile_px)
                        for t in D.local_tile_ids(w.W, w.H, args.tile_px, rank, world) if t * args.tile_px < n_px)
         res["local_samples"] = local_px * w.spp
+        # what every rank did, as seen by the collective itself: [rank, device, kernel ms, samples] all-gathered over the process group
+        mine = torch.tensor([float(rank), float(dev), res["k_ms"], float(res["local_samples"])], dtype=torch.float64, device=cdev)
+        rows = [mine.clone() for _ in range(world)]
+        if world > 1:
+            dist.all_gather(rows, mine)
+        res["ranks"] = {"ranks_seen": dist.get_world_size() if world > 1 else 1, "devices": [int(r[1].item()) for r in rows],
+                        "kernel_ms": [float(r[2].item()) for r in rows], "local_samples": [int(r[3].item()) for r in rows],
+                        "hosts_rank_ids": [int(r[0].item()) for r in rows]}
+        if rank == 0:
+            assert frame is not None and tuple(frame.shape) == (w.H, w.W, 3)
+            res["mean_radiance"] = float(torch.nan_to_num(frame).mean().item()) / w.spp
+            res["multi_check"] = check_rows(b, cam, bg, w, frame[w.H // 2: w.H // 2 + 2].cpu().numpy())
         del tr, frame, b
         torch.cuda.empty_cache()
         return res
@@ -350,10 +385,21 @@ def main():
         k_total_ms, k_launches = R.kernel_time_total(b)
         assert k_launches == steps * n_gpus
         frame = R.multi_frame(b, w.W, w.H)
+        rk = R.last_multi_ranks(b)             # the last frame's ranks as the library ran them: device, kernel ms; ranks in RCCL's communicator
+        n_px = w.W * w.H
+        tile_px = args.tile_px or D.DEFAULT_TILE_PX
+        per_rank = [sum(max(0, min(n_px, (t + 1) * tile_px) - t * tile_px) for t in D.local_tile_ids(w.W, w.H, tile_px, r, n_gpus) if t * tile_px < n_px) * w.spp
+                    for r in range(n_gpus)]
         res = {"w": w, "elapsed": elapsed, "steps": steps, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
                "pipeline": 1, "multi_ms": R.last_multi_ms(b), "mean_radiance": float(np.nan_to_num(frame).mean()) / w.spp,
                "local_samples": w.samples / n_gpus,            # per launch: k_ms is the mean over the frame's N launches, so is this
-               "stats_scope": "frame"}                         # rt_last_stats sums the counters of the frame's N launches
+               "stats_scope": "frame",                         # rt_last_stats sums the counters of the frame's N launches
+               "ranks": {"ranks_seen": rk["collective_ranks"] if rk["collective_ranks"] else rk["n_ranks"],
+                         "ranks_seen_source": "ncclCommCount of the gather's communicator" if rk["collective_ranks"] else
+                                              "launches of the frame (no collective ran: virtual ranks on one device)",
+                         "devices": rk["devices"], "kernel_ms": rk["kernel_ms"], "local_samples": per_rank}}
+        torch.cuda.set_device(rk["devices"][0] if rk["devices"] else 0)
+        res["multi_check"] = check_rows(b, cam, bg, w, frame[w.H // 2: w.H // 2 + 2])
         del b
         torch.cuda.empty_cache()
         return res
@@ -386,7 +432,8 @@ def main():
             ro, va = roofline_of(we, r["local_samples"], r["k_ms"], r["n_flush"], kernel_name_of(we, args.f32), with_pmc)
             others[we.key] = {"workload": we.describe(), "value": we.samples * r["steps"] / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": r["steps"],
                               "warmup": f"1 frame at {max(1, we.spp // 32)} spp (same kernel and scene)", "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
-                              "kernel_ms": r["k_ms"], "frac": ro["frac"], "ops_per_sample": ro["ops_per_sample"], "achieved_Tops": ro["achieved"],
+                              "kernel_ms": r["k_ms"], "frac": ro["frac"], "frac_unweighted": ro["frac_unweighted"], "frac_of_measured_issue": ro["frac_of_measured_issue"],
+                              "achieved_unweighted_TFLOPs": ro["achieved_unweighted_TFLOPs"], "ops_per_sample": ro["ops_per_sample"], "achieved_Tops": ro["achieved"],
                               "model_hbm_ratio": ro["model_hbm"]["ratio"], "exceeds_hbm_peak": ro["model_hbm"]["exceeds_hbm_peak"],
                               "hbm_measured_GBps": ro["hbm_measured_GBps"], "hbm_measured_frac": ro["hbm_measured_frac"],
                               "bytes_per_sample": ro["model_hbm"]["bytes_per_sample"],
@@ -394,7 +441,7 @@ def main():
                               "valu_pmc": va, "kernel": ro["kernel"], "multi_ms": r["multi_ms"],
                               "lane_utilisation": r["stats"]["live_lane_iterations"] / max(1, 64 * r["stats"]["wave_iterations"]),
                               "nonfinite_samples": r["stats"]["nonfinite_samples"], "nonfinite_samples_scope": r["stats_scope"],
-                              "mean_radiance": r["mean_radiance"]}
+                              "mean_radiance": r["mean_radiance"], "multi_check": r.get("multi_check"), "ranks": r.get("ranks")}
         if inproc:
             par = (f"one process, rt_render_multi_device: {n_gpus} " + ("VIRTUAL ranks on one device (RT_MULTI_VIRTUAL_RANKS test hook: the decomposition, "
                    "not a measurement; device-to-device copies stand in for the gather)" if virtual else "GPUs, ncclCommInitAll + 1 ncclGather + un-permute on device 0"))
@@ -420,6 +467,15 @@ def main():
                                      for pl, r in tried.items()}
         if main_res["multi_ms"] is not None:
             out["multi_ms_last_frame"] = main_res["multi_ms"]
+        # self-validation (outside the timed region): two rows of the timed frame against a plain one-device render of those rows, and
+        # what each rank did.  `multi_ok` is false if any workload's check failed, a rank rendered nothing, or fewer ranks than asked ran.
+        out["multi_check"] = main_res.get("multi_check")
+        out["ranks"] = main_res.get("ranks")
+        checks = [main_res.get("multi_check")] + [r.get("multi_check") for r in extra]
+        rk = main_res.get("ranks") or {}
+        out["multi_ok"] = bool(all(c and c["ok"] for c in checks) and rk.get("ranks_seen") == n_gpus and len(rk.get("kernel_ms", [])) == n_gpus
+                               and all(k > 0.0 for k in rk.get("kernel_ms", [])) and all(x > 0 for x in rk.get("local_samples", []))
+                               and (virtual or len(set(rk.get("devices", []))) == n_gpus))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -52,7 +52,7 @@ enum {
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
     RT_SPECULATE_BVH = 1024, /* scheduling only, same samples (lock-step BVH kernel): a lane that has reached a leaf walks on while it waits for the
-                              leaf step (rt_kernel.hip: bvh_hit_spec).  Chosen automatically for scenes whose world is one BVH (every ray
+                              leaf step (rt_kernel.hip: bvh_hit_filt, SPEC).  Chosen automatically for scenes whose world is one BVH (every ray
                               enters it); this flag forces it on ...                                                          */
     RT_NO_SPECULATE_BVH = 2048, /* ... and this one off                                                                        */
     RT_ISOTROPIC_SCATTER = 4 /* opt-in, NOT the committed reference behaviour: Isotropic (constant media) scatters with its
@@ -191,6 +191,13 @@ int rt_render_multi_device(rt_scene*, const rt_camera*, const double background[
 int rt_multi_sync(rt_scene*);
 int rt_multi_copy_frame(rt_scene*, double* rgb_sum_out, size_t n_doubles);
 int rt_last_multi_ms(rt_scene*, double out4[4]);
+/* The ranks of the most recent rt_render_multi* frame (waits for it): *n_ranks_out = how many launches made the frame; for the first
+ * max_ranks of them device_out[r] = the HIP device rank r ran on, kernel_ms_out[r] = its path-tracing kernel's duration (HIP events
+ * on its stream; -1 if no longer known); *collective_ranks_out = the size RCCL reports for the communicator the frame's gather ran
+ * on (ncclCommCount), 0 when no collective ran (one device without RT_MULTI_COLLECTIVE, or the virtual-rank test hook).  What a
+ * multi-GPU caller checks before it trusts a frame: N distinct devices, N ranks in the collective, no rank with a ~0 ms kernel. */
+int rt_last_multi_ranks(rt_scene*, uint32_t max_ranks, uint32_t* n_ranks_out, int* device_out, double* kernel_ms_out,
+                        uint32_t* collective_ranks_out);
 /* How BVH objects are built when the scene is flattened (at the first render / rt_scene_prepare after a change).
  * RT_BVH_MEDIAN (default) is BVH::new, src/bvh.rs:18-73: widest axis, object median.  RT_BVH_SAH is an opt-in fast mode
  * (binned surface-area heuristic, one object per leaf as in the reference): same closest hits; the order in which
@@ -237,7 +244,9 @@ int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
 int rt_debug_bvh_links(rt_scene*, uint32_t* out, uint32_t max_nodes, uint32_t* roots_out, uint32_t max_roots, uint32_t* n_roots_out);
 /* Test aid: AABB::hit (src/aabb.rs:19-36) evaluated on the device for n (box, ray, [t_min, t_max]) triples given as host arrays
  * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
- * traversal uses for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300).  Non-zero on a HIP error. */
+ * leaf steps use for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300); bit 3: ray and box are inside the
+ * ranges of the box steps' conservative f32 filter (rt_kernel.hip: make_filter); bit 4: that filter lets the box through (it must
+ * wherever bit 0 is set; it may elsewhere).  Non-zero on a HIP error. */
 int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out);
 /* Debugging aid for parity work: the hits of ONE camera path, level by level.  rt_debug_trace_path chooses the path (local pixel index =
  * output-order pixel for an unsharded render, sample index; -1 switches it off); the following renders record, per level of ray_color

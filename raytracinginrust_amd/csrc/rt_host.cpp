@@ -449,6 +449,7 @@ static int settle_slot(Scene& s, Scene::LaunchSlot& l) {
     float ms = 0.f;
     HIP_OK(hipEventElapsedTime(&ms, (hipEvent_t)l.ev_start, (hipEvent_t)l.ev_stop));
     s.kernel_ms_total += ms; s.kernel_launches_timed++;
+    s.seq_ms[l.seq % Scene::SEQ_RING] = ms; s.seq_tag[l.seq % Scene::SEQ_RING] = l.seq;
     l.timed = true;
     return 0;
 }
@@ -727,6 +728,10 @@ int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
     HIP_OK(hipDeviceSynchronize());
     return 0;
 }
+int settle_all_launches(Scene& s) {
+    for (Scene::DeviceCtx* c : s.ctxs) { DeviceGuard guard(c->device); for (Scene::LaunchSlot& l : c->slots) if (settle_slot(s, l)) return -1; }
+    return 0;
+}
 bool flatten_for_render(Scene& s) { if (flatten_scene(s)) return true; set_err(s.error); return false; }
 int device_kernel_ms(Scene& s, int device, float* ms) {
     for (Scene::DeviceCtx* c : s.ctxs) if (c->device == device && c->last_slot >= 0) {
@@ -756,7 +761,7 @@ int rt_last_kernel_ms(rt_scene* sc, float* ms_out) {
 // for the launches still in flight.  For callers that keep several frames in flight and must not stop after each one.
 int rt_kernel_time_total(rt_scene* sc, double* ms_total, unsigned long long* n_launches, int reset) {
     if (!sc) return set_err("null argument");
-    for (Scene::DeviceCtx* c : sc->s.ctxs) { DeviceGuard guard(c->device); for (Scene::LaunchSlot& l : c->slots) if (settle_slot(sc->s, l)) return -1; }
+    if (settle_all_launches(sc->s)) return -1;
     if (ms_total) *ms_total = sc->s.kernel_ms_total;
     if (n_launches) *n_launches = sc->s.kernel_launches_timed;
     if (reset) { sc->s.kernel_ms_total = 0.0; sc->s.kernel_launches_timed = 0; }

@@ -47,6 +47,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Gather)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(comm_t, int*) = nullptr;        // optional: how many ranks the communicator really has (rt_last_multi_ranks)
     std::string err;
 };
 const int NCCL_DOUBLE = 8;                      // ncclFloat64, rccl.h ncclDataType_t
@@ -65,6 +66,7 @@ Rccl* rccl() {
     r.GroupEnd = (int (*)())dlsym(r.lib, "ncclGroupEnd");
     r.Gather = (int (*)(const void*, void*, size_t, int, int, comm_t, hipStream_t))dlsym(r.lib, "ncclGather");
     r.GetErrorString = (const char* (*)(int))dlsym(r.lib, "ncclGetErrorString");
+    r.CommCount = (int (*)(comm_t, int*))dlsym(r.lib, "ncclCommCount");
     if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.Gather || !r.GetErrorString) {
         r.err = "librccl.so.1 lacks ncclCommInitAll / ncclGather / ncclGroupStart / ncclGroupEnd";
         r.lib = nullptr;
@@ -238,12 +240,14 @@ bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint3
     // ---- every device: its share of the tiles, asynchronously on its own stream (one thread: a launch is a few microseconds)
     s.frame_group++; s.group_open = true;          // the N launches are ONE frame: rt_last_stats sums their counters
     struct CloseGroup { Scene& s; ~CloseGroup() { s.group_open = false; } } close_group{s};
+    s.multi_rank_seq.assign(N, 0ull); s.multi_rank_dev.assign(N, -1); s.multi_comm_count = 0;
     for (uint32_t r = 0; r < N; r++) {
         if ((e = hipSetDevice(devs[r])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
         if ((long)r == fail_rank) { err = "rank " + std::to_string(r) + ": injected failure (RT_MULTI_FAIL_RANK)"; return false; }
         if (rt_render_device(sc, cam, bg, W, H, spp, max_depth, seed, flags & ~(uint32_t)RT_MULTI_COLLECTIVE, tile_px, r, N, rank_tiles[r], tiles_bytes, ctx[r]->stream)) {
             err = "rank " + std::to_string(r) + " (device " + std::to_string(devs[r]) + "): " + rt_last_error(); return false;
         }
+        s.multi_rank_seq[r] = s.launch_seq; s.multi_rank_dev[r] = devs[r];
     }
     // ---- one gather to the root device (rank 0), each rank's part ordered behind its own kernel on its own stream
     if ((e = hipSetDevice(devs[0])) != hipSuccess) { err = hip_msg("hipSetDevice", e); return false; }
@@ -257,6 +261,8 @@ bool enqueue_frame(rt_scene* sc, const rt_camera* cam, const double bg[3], uint3
         const int ge = R->GroupEnd();                                 // always closed, also after a failed ncclGather
         if (g != 0) { err = std::string("ncclGather: ") + R->GetErrorString(g); return false; }
         if (ge != 0) { err = std::string("ncclGroupEnd: ") + R->GetErrorString(ge); return false; }
+        int cnt = 0;
+        s.multi_comm_count = (R->CommCount && R->CommCount(s.comms[0], &cnt) == 0) ? cnt : (int)N;
     } else if (virtual_ranks) {
         for (uint32_t r = 0; r < N; r++)
             if ((e = hipMemcpyAsync((char*)root.d_gather + (size_t)r * tiles_bytes, rank_tiles[r], tiles_bytes, hipMemcpyDeviceToDevice, rs)) != hipSuccess) { err = hip_msg("hipMemcpyAsync", e); return false; }
@@ -368,6 +374,24 @@ int rt_render_multi(rt_scene* sc, const rt_camera* cam, const double bg[3], uint
     const double t0 = sc->s.multi_t0;
     if (rt_multi_copy_frame(sc, rgb_sum_out, (size_t)W * H * 3)) return -1;
     sc->s.multi_ms[3] = now_ms() - t0;              // the whole call, transfer to the host included
+    return 0;
+}
+
+// The ranks of the last rt_render_multi* frame (waits for it): HIP device and kernel time of each, and how many ranks the communicator
+// of its gather has according to RCCL (0: no collective ran).  For a caller that must see a rank that rendered nothing, a device used
+// twice, or a communicator smaller than the node.
+int rt_last_multi_ranks(rt_scene* sc, uint32_t max_ranks, uint32_t* n_ranks_out, int* device_out, double* kernel_ms_out, uint32_t* collective_ranks_out) {
+    if (!sc || !n_ranks_out) return set_error("null argument");
+    Scene& s = sc->s;
+    if (settle(s)) return -1;
+    if (settle_all_launches(s)) return -1;
+    *n_ranks_out = (uint32_t)s.multi_rank_seq.size();
+    if (collective_ranks_out) *collective_ranks_out = (uint32_t)s.multi_comm_count;
+    for (uint32_t r = 0; r < s.multi_rank_seq.size() && r < max_ranks; r++) {
+        const unsigned long long q = s.multi_rank_seq[r];
+        if (device_out) device_out[r] = s.multi_rank_dev[r];
+        if (kernel_ms_out) kernel_ms_out[r] = (q != 0ull && s.seq_tag[q % Scene::SEQ_RING] == q) ? s.seq_ms[q % Scene::SEQ_RING] : -1.0;
+    }
     return 0;
 }
 

@@ -99,6 +99,12 @@ struct Scene {
     void* multi_ev[4] = {nullptr, nullptr, nullptr, nullptr}; int multi_ev_device = -1;
     std::vector<void*> virtual_tiles; size_t virtual_tiles_bytes = 0; int virtual_tiles_device = -1;
     double kernel_ms_total = 0.0; unsigned long long kernel_launches_timed = 0;      // rt_kernel_time_total
+    // per-launch kernel times by launch number (a small ring: a slot's events are reused by later launches) and, for the last
+    // rt_render_multi* frame, the launch number / HIP device of every rank and the size RCCL reports for the communicator the gather
+    // ran on (0: no collective ran — one device, or the virtual-rank test hook) — rt_last_multi_ranks
+    static const int SEQ_RING = 64;
+    double seq_ms[SEQ_RING] = {0}; unsigned long long seq_tag[SEQ_RING] = {0};
+    std::vector<unsigned long long> multi_rank_seq; std::vector<int> multi_rank_dev; int multi_comm_count = 0;
     // One frame may be several launches (rt_render_multi: one per device or virtual rank).  Every launch carries its frame's number;
     // the counters of a frame's launches are summed in acc_stats (rt_last_stats reports the whole frame, not one rank's share).
     unsigned long long frame_group = 0; bool group_open = false;      // group_open: rt_render_multi is enqueueing the launches of ONE frame
@@ -121,6 +127,7 @@ bool flatten_scene(Scene& s);
 // rt_host.cpp (shared with rt_multi.cpp)
 int set_error(const std::string& m);                              // leaves the message for rt_last_error(); returns -1
 int device_kernel_ms(Scene& s, int device, float* ms);            // duration of the last path-tracing kernel launched on `device`
+int settle_all_launches(Scene& s);                                // wait for every launch in flight; its kernel time joins the totals and the per-launch ring
 int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags); // rt_scene_prepare's work for one device (current device = c.device)
 bool flatten_for_render(Scene& s);                                // flatten_scene + rt_last_error on failure
 void multi_release(Scene& s);                                     // rt_multi.cpp: destroys the cached RCCL communicators

@@ -132,6 +132,20 @@ def last_multi_ms(b: SceneBuilder) -> dict:
     return {"slowest_kernel_ms": ms[0], "gather_ms": ms[1], "unpermute_ms": ms[2], "call_ms": ms[3]}
 
 
+def last_multi_ranks(b: SceneBuilder) -> dict:
+    """rt_last_multi_ranks: HIP device and kernel ms of every rank of the last rt_render_multi* frame, and the rank count RCCL
+    reports for the communicator its gather ran on (0: no collective ran)."""
+    be = _lib.load()
+    n, coll = C.c_uint32(), C.c_uint32()
+    dev = (C.c_int * 64)(); ms = (C.c_double * 64)()
+    be.lib.rt_last_multi_ranks.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    if be.lib.rt_last_multi_ranks(b.h, 64, C.byref(n), dev, ms, C.byref(coll)) != 0:
+        raise RenderError(_err(be))
+    k = min(int(n.value), 64)
+    return {"n_ranks": int(n.value), "devices": [int(dev[i]) for i in range(k)], "kernel_ms": [float(ms[i]) for i in range(k)],
+            "collective_ranks": int(coll.value)}
+
+
 def local_tiles(W: int, H: int, tile_px: int, rank: int, world: int) -> int:
     return int(_lib.load().lib.rt_local_tiles(W, H, tile_px, rank, world))
 

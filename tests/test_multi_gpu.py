@@ -135,6 +135,26 @@ def test_render_multi_failure_leaves_nothing_behind(pbe, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_last_multi_ranks_reports_every_rank(pbe, monkeypatch):
+    """rt_last_multi_ranks: per rank of the last rt_render_multi* frame the HIP device and the kernel time (also when 8 virtual ranks
+    reuse a stream's two launch slots), and the size RCCL itself reports for the communicator the gather ran on."""
+    b, cam, bg = scenes.cornell_box(pbe)
+    W, H, spp, depth = 160, 120, 16, 20
+    R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1, flags=R.RT_MULTI_COLLECTIVE)
+    rk = R.last_multi_ranks(b)
+    assert rk["n_ranks"] == 1 and rk["devices"] == [0] and rk["collective_ranks"] == 1 and rk["kernel_ms"][0] > 0.0
+    R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
+    assert R.last_multi_ranks(b)["collective_ranks"] == 0                  # one device, no collective asked for
+    for n in (3, 8):
+        monkeypatch.setenv("RT_MULTI_VIRTUAL_RANKS", str(n))
+        R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
+        rk = R.last_multi_ranks(b)
+        assert rk["n_ranks"] == n and rk["devices"] == [0] * n and rk["collective_ranks"] == 0
+        assert all(k > 0.0 for k in rk["kernel_ms"]) and max(rk["kernel_ms"]) < 50.0
+    monkeypatch.delenv("RT_MULTI_VIRTUAL_RANKS")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gpus", [2, 8])
 def test_bench_runs_in_process_without_a_launcher(gpus):
     """`python bench.py --gpus N` with no launcher (what the driver's SCALE run may use): the in-process mode through
@@ -155,6 +175,14 @@ def test_bench_runs_in_process_without_a_launcher(gpus):
     assert d["roofline"]["bound"] == "f64_valu" and 0 < d["roofline"]["frac"] <= 1 and d["cpu_baseline"] is None
     assert set(d["multi_ms_last_frame"]) == {"slowest_kernel_ms", "gather_ms", "unpermute_ms", "call_ms"}
     assert 0.13 < d["mean_radiance"] < 0.18 and "C1" in d["workloads"]          # the Cornell frame's mean per channel (oracle: 0.155)
+    # round 5: the line validates itself — two rows of the timed frame against a plain one-device render of those rows, every rank's
+    # device / kernel time / share, the number of ranks that took part (here: launches, no collective runs between virtual ranks)
+    mc, rk = d["multi_check"], d["ranks"]
+    assert mc["ok"] and mc["rows"] == [400, 401] and mc["max_abs_diff"] <= 1e-12 * (1024 + 1024 * 15.0)
+    assert d["workloads"]["C1"]["multi_check"]["ok"] and d["workloads"]["C1"]["ranks"]["ranks_seen"] == gpus
+    assert rk["ranks_seen"] == gpus and len(rk["devices"]) == gpus and len(rk["kernel_ms"]) == gpus and all(k > 0 for k in rk["kernel_ms"])
+    assert sum(rk["local_samples"]) == 800 * 800 * 1024 and max(rk["local_samples"]) / min(rk["local_samples"]) < 1.01
+    assert d["multi_ok"] is True
 
 
 @pytest.mark.gpu
@@ -180,6 +208,12 @@ def test_bench_runs_one_process_per_gpu_under_the_launcher():
     assert d["ms_per_step"] == min(v["ms_per_step"] for v in d["pipeline_tried"].values())
     assert abs(d["value"] - 800 * 800 * 1024 / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
     assert d["cpu_baseline"] is None and d["roofline"]["traffic"] is None and 0.13 < d["mean_radiance"] < 0.18
+    mc, rk = d["multi_check"], d["ranks"]
+    assert mc["ok"] and mc["rows"] == [400, 401]
+    assert rk["ranks_seen"] == 2 and rk["hosts_rank_ids"] == [0, 1] and all(k > 0 for k in rk["kernel_ms"]) and sum(rk["local_samples"]) == 800 * 800 * 1024
+    assert d["workloads"]["C1"]["multi_check"]["ok"]
+    # (two ranks share the one GPU here, so `multi_ok` — which asks for N distinct devices — is false by design on this box)
+    assert d["multi_ok"] is False and rk["devices"] == [0, 0]
 
 
 @pytest.mark.gpu
