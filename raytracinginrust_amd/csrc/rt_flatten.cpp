@@ -236,9 +236,9 @@ struct Flattener {
     // ---- world flattening
     struct Chain { DOp<double> ops[RT_MAX_OPS]; int n = 0; };
 
-    bool emit_object(uint32_t kind, uint32_t first, uint32_t count, const Chain& chain, int medium) {
+    bool emit_object(uint32_t kind, uint32_t first, uint32_t count, const Chain& chain, int medium, bool is_cube = false) {
         DObject o{};
-        o.geom_kind = kind; o.geom_first = first; o.geom_count = count;
+        o.geom_kind = kind; o.geom_first = first; o.geom_count = count; o.is_cube = is_cube ? 1u : 0u;
         o.first_op = (uint32_t)f.ops.size(); o.n_ops = (uint32_t)chain.n; o.medium = medium;
         for (int i = 0; i < chain.n; i++) f.ops.push_back(chain.ops[i]);
         f.objects.push_back(o);
@@ -252,7 +252,7 @@ struct Flattener {
         switch (h.kind) {
         case HNode::SPHERE: case HNode::MSPHERE: case HNode::RECT: case HNode::TRI: case HNode::CUBE:
             simple_geom(n, kind, first, count);
-            return emit_object(kind, first, count, chain, medium);
+            return emit_object(kind, first, count, chain, medium, h.kind == HNode::CUBE);
         case HNode::LIST: {
             // HittableList::hit (hit.rs:59-71) keeps the closest hit, later items winning ties, and wrappers
             // act per hit, so Wrapper(List[a,b]) == List[Wrapper(a), Wrapper(b)].  A ConstantMedium boundary
@@ -470,6 +470,14 @@ bool flatten_scene(Scene& s) {
         for (int k = 0; k < 3; k++)
             if (!(std::fabs(nd.mn[k]) < 1e300 && std::fabs(nd.mx[k]) < 1e300 && nd.mn[k] <= nd.mx[k])) s.flat.bvh_tame = false;
     make_filter_nodes(s.flat);
+    {   // the Cube fast path's scene-wide bound; off when a Cube is inverted on some axis (its six rects then never report a hit
+        // through the bounds test, which the fast path's slab logic does not model) or a rect is not finite
+        float m = 1.0f; bool ok = true;
+        for (const DRect<double>& r : s.flat.rects)
+            for (double v : {r.a0, r.a1, r.b0, r.b1, r.k}) { ok = ok && std::isfinite(v) && std::fabs(v) <= 0x1p40; m = std::fmax(m, (float)std::fabs(v) * 1.0000002f); }
+        for (const HNode& h : s.nodes) if (h.kind == HNode::CUBE) for (int k = 0; k < 3; k++) ok = ok && h.v[k] <= h.v[3 + k];
+        s.flat.rect_m = ok ? m : 0.0f;
+    }
     s.flat_valid = true;
     return true;
 }

@@ -553,7 +553,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
     P.n_bvh = (uint32_t)f.bvh.size();
-    P.bvh_f = (const DFNode*)d.bvh_f; P.filter_m = f.filter_m;
+    P.bvh_f = (const DFNode*)d.bvh_f; P.filter_m = f.filter_m; P.rect_m = f.rect_m;
     P.materials = (const DMaterial<T>*)d.materials; P.textures = (const DTexture<T>*)d.textures; P.media = (const DMedium<T>*)d.media;
     P.lights = (const DLight*)d.lights; P.n_lights = (uint32_t)f.lights.size();
     P.perlins = (const DPerlin<T>*)d.perlins; P.pbr = (const DPbr<T>*)d.pbr; P.image_bytes = (const uint8_t*)d.image;

@@ -59,7 +59,7 @@ template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad;
 template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
-struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t pad0, pad1; };
+struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t is_cube, pad1; };   // is_cube: the 6 rects are ONE Cube's faces in cube.rs:17-24 order (a run of six bare AARects is not)
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 // Conservative f32 companion of a BVH node (same id, same skip link), what the f64 kernels' box steps read (rt_kernel.hip: "filtered walk"):
 // b = {min.x, max.x, min.y, max.y, min.z, max.z} rounded OUTWARD to f32; info = left child id (inner) or own id | FNODE_LEAF (leaf).
@@ -124,6 +124,9 @@ template <typename T> struct KParams {
     // filtered walk (f64 kernels, reference traversal order): the f32 companions of bvh[] — the first n_cached of THEM are what the
     // workgroups stage in LDS then — and filter_m >= every |coordinate| of theirs (>= 1; 0 = no filter: some box is non-finite or huge)
     const DFNode* bvh_f; float filter_m;
+    // Cube fast path (rt_kernel.hip: cube_hit): >= every |coordinate| of every rect; 0 = off (a Cube with min > max on some axis, or a
+    // non-finite coordinate: the six exact tests then)
+    float rect_m;
 };
 
 } // namespace rt

@@ -220,6 +220,16 @@ DEV double m_abs(double x) { return ::fabs(x); }  DEV float m_abs(float x) { ret
 DEV double m_max(double a, double b) { return ::fmax(a, b); } DEV float m_max(float a, float b) { return ::fmaxf(a, b); }   // f64::max: NaN-ignoring
 DEV double m_min(double a, double b) { return ::fmin(a, b); } DEV float m_min(float a, float b) { return ::fminf(a, b); }
 
+// min / max of two numbers known not to be NaN: the bare instruction (fmin / fmax would first quiet each operand with a v_max x, x)
+DEV double min_nn(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV double max_nn(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float min_nn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float max_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEV float max3_nn(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV float min3_nn(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV float med3_nn(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+DEV float amax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+
 template <typename T> struct Lim;
 template <> struct Lim<double> { static DEV double max() { return 1.7976931348623157e308; } static DEV double inf() { return __longlong_as_double(0x7FF0000000000000LL); } };
 template <> struct Lim<float> { static DEV float max() { return 3.402823466e38f; } static DEV float inf() { return __uint_as_float(0x7F800000u); } };
@@ -294,12 +304,84 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
     return true;
 }
 
+// ------------------------------------------------------------------ Cube::hit: one exact rect test instead of six
+// Cube::hit is HittableList::hit over the six faces (cube.rs:14-36): six times t = (k - o_k) / d_k, the range test, the bounds test.
+// Its result is the accepted face with the smallest t.  The six plane distances are first computed APPROXIMATELY (the exact f64
+// numerators k - o_k, converted to f32, times v_rcp_f32 of d_k: relative error <= 2^-21.5) and, when every comparison that decides the
+// outcome is clear of that error, the answer is known without a division: the ray enters the box at s1 = max of the three per-axis
+// nearer planes and leaves at e1 = min of the farther ones; if s1 > e1 no face is hit at all; otherwise only the entry and the exit
+// face pass their bounds tests, and the winner is the entry face if its t lies in [t_min, closest], else the exit face if its t does.
+// That ONE face then gets the reference's exact test — the same division, the same `o + t d` and comparisons (rect.rs:49-60), so the t
+// that is kept is the reference's — and the other five divisions are never made.
+// CLEAR means: with mu = RHO Tm + A (Tm = the largest magnitude among s1, e1 and the runners-up s2, e2), s1 - s2 > mu, e2 - e1 > mu and
+// |e1 - s1| > mu; and s1 (or e1) lies inside or outside [t_min, closest] by more than RHO (|v| + |bound|).  Why that is enough:
+//   * a face's bounds test on axis a compares p_a = fl(o_a + fl(t d_a)) with the box: in exact arithmetic that is t against slab a's
+//     two plane distances, and fl() moves p_a by at most 2^-52 (|o_a| + |t d_a|), i.e. t's side of a plane distance v is decided
+//     correctly whenever |t - v| > 2^-52 (|t| + |v| + M_a / |d_a|); A = 2^-40 max_a M_a |1/d_a| and RHO = 2^-18 >= 8 * 2^-21.5 cover that
+//     and both approximation errors, for the pairs tested directly and — RHO being 8x what a pair needs — for the third-ranked
+//     planes too (|v| <= 7 Tm: mu is already the pair's margin; |v| > 7 Tm: the gap is > 6/7 |v|, the margin < 1/2 |v|);
+//   * so for a clear lane the ORDER of the six exact distances is the approximate one, every face other than entry / exit fails a
+//     bounds test exactly, and entry / exit pass theirs iff s1 < e1; the range tests are decided the same way; the list's running
+//     closest only ever drops to the exit face's t before the entry face is tried, which is larger: the entry face still wins.
+// Anything not clear — a ray through an edge, a grazing ray, a thin box, a zero or denormal direction component (inf / NaN fail
+// every comparison), t within a few ppm of t_min or closest — makes the WAVE take the six exact tests (range_hit's loop) instead.
+// Returns false when some lane of the wave is not clear (the caller runs the exact loop for everybody; nothing was changed).
+// (KParams::rect_m >= every |coordinate| of every rect — a scene-wide M_a — and is 0 when some Cube has min > max: no fast path then.)
+DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
+    const DRect<double> f0 = ld_rect(P.rects + first);                  // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
+    const double mnz = cl(&P.rects[first + 1u].k);                      // XY face at z = min.z (cube.rs:18)
+    const double mnx = f0.a0, mxx = f0.a1, mny = f0.b0, mxy = f0.b1, mxz = f0.k;
+    const float rx = __builtin_amdgcn_rcpf((float)ray.d.x), ry = __builtin_amdgcn_rcpf((float)ray.d.y), rz = __builtin_amdgcn_rcpf((float)ray.d.z);
+    // the six plane distances, approximately: the exact numerator k - o_k of rect.rs:50, rounded to f32, times the approximate 1 / d_k
+    const float ax0 = (float)(mnx - ray.o.x) * rx, ax1 = (float)(mxx - ray.o.x) * rx;
+    const float ay0 = (float)(mny - ray.o.y) * ry, ay1 = (float)(mxy - ray.o.y) * ry;
+    const float az0 = (float)(mnz - ray.o.z) * rz, az1 = (float)(mxz - ray.o.z) * rz;
+    const float nrx = min_nn(ax0, ax1), frx = max_nn(ax0, ax1), nry = min_nn(ay0, ay1), fry = max_nn(ay0, ay1), nrz = min_nn(az0, az1), frz = max_nn(az0, az1);
+    const float s1 = max3_nn(nrx, nry, nrz), s2 = med3_nn(nrx, nry, nrz), e1 = min3_nn(frx, fry, frz), e2 = med3_nn(frx, fry, frz);
+    const float RHO = 0x1p-18f;
+    const float A = (0x1p-40f * P.rect_m) * amax3(rx, ry, rz);
+    const float mu = __builtin_fmaf(RHO, __builtin_fmaxf(amax3(s1, e1, s2), __builtin_fabsf(e2)), A);
+    const bool order_clear = P.rect_m > 0.0f && s1 - s2 > mu && e2 - e1 > mu;
+    const bool through = e1 - s1 > mu, past = s1 - e1 > mu;              // enters before it leaves: the box is hit / leaves first: it is missed
+    // a plane distance against [t_min, t_max], by more than the approximations can be off
+    const float lo = __builtin_fmaxf((float)t_min, -1.0e37f), hi = __builtin_fminf((float)t_max, 1.0e37f);
+    const float gl = RHO * __builtin_fabsf(lo), gh = RHO * __builtin_fabsf(hi);
+    const float g1 = RHO * __builtin_fabsf(s1), g2 = RHO * __builtin_fabsf(e1);
+    const bool en_in = s1 - lo > g1 + gl && hi - s1 > g1 + gh, en_out = lo - s1 > g1 + gl || s1 - hi > g1 + gh;
+    const bool ex_in = e1 - lo > g2 + gl && hi - e1 > g2 + gh, ex_out = lo - e1 > g2 + gl || e1 - hi > g2 + gh;
+    const bool clear = order_clear && (past || (through && (en_in || (en_out && (ex_in || ex_out)))));
+    if (__ballot(!clear) != 0ull) return false;
+    const bool cand = through && (en_in || ex_in);
+    if (__ballot(cand) == 0ull) return true;                              // nobody's ray has a face to test
+    if (cand) {
+        // which face: the axis of the chosen distance; of that axis' two planes the entry one is min's where d > 0, max's where d < 0
+        const bool use_exit = !en_in;
+        const bool on_x = use_exit ? e1 == frx : s1 == nrx, on_y = !on_x && (use_exit ? e1 == fry : s1 == nry), on_z = !on_x && !on_y;
+        const double den = on_x ? ray.d.x : (on_y ? ray.d.y : ray.d.z), org = on_x ? ray.o.x : (on_y ? ray.o.y : ray.o.z);
+        const bool hi_side = (den < 0.0) != use_exit;
+        const double k = hi_side ? (on_x ? mxx : (on_y ? mxy : mxz)) : (on_x ? mnx : (on_y ? mny : mnz));
+        const double t = (k - org) / den;                                 // rect.rs:50
+        if (!(t < t_min || t > t_max)) {                                  // rect.rs:51-53
+            const double px = ray.o.x + t * ray.d.x, py = ray.o.y + t * ray.d.y, pz = ray.o.z + t * ray.d.z;          // rect.rs:54-55, the two axes that are not the face's
+            const bool out_x = px < mnx || px > mxx, out_y = py < mny || py > mxy, out_z = pz < mnz || pz > mxz;      // rect.rs:56-58
+            if (!((out_x && !on_x) || (out_y && !on_y) || (out_z && !on_z))) {
+                t_out = t; any = true;
+                prim_out = (G_RECT << 28) | (first + (on_x ? 4u : (on_y ? 2u : 0u)) + (hi_side ? 0u : 1u));            // cube.rs:17-24: (XY, XZ, YZ) x (max, min)
+            }
+        }
+    }
+    return true;
+}
+
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
-DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false) {
     bool any = false;
     T closest = t_max;
+    if constexpr (sizeof(T) == 8u) {
+        if (kind == G_RECT && is_cube && cube_hit(P, first, ray, t_min, t_max, closest, prim_out, any)) { t_out = closest; return any; }
+    }
     if (kind == G_RECT) {
         // software-pipelined record fetch: record i+1 is requested before record i is tested (the table carries one
         // padding record), so a scalar load's latency overlaps a whole rect test instead of stalling each iteration
@@ -384,11 +466,6 @@ template <typename T> DEV bool box_inside_exact(const DBvhNode<T>& nd, V3<T> o, 
     }
     return inside;
 }
-// min / max of two numbers known not to be NaN: the bare instruction (fmin / fmax would first quiet each operand with a v_max x, x)
-DEV double min_nn(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-DEV double max_nn(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-DEV float min_nn(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-DEV float max_nn(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <typename T> DEV bool box_inside_tame(const DBvhNode<T>& nd, V3<T> o, V3<T> inv, T t_min, T closest) {
     const T ax = (nd.mn[0] - o.x) * inv.x, bx = (nd.mx[0] - o.x) * inv.x;
     const T ay = (nd.mn[1] - o.y) * inv.y, by = (nd.mx[1] - o.y) * inv.y;
@@ -447,8 +524,6 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
 // M <= 2^40 (host: KParams::filter_m, >= 1): products stay below 2^82 and E_j above 2^-62, so no overflow, and an underflow (< 2^-126)
 // anywhere is far inside E_j.  A NaN closest hit (never seen) converts to a quiet NaN, which v_min_f32 ignores: conservative.
 struct BoxFilter { float ix, iy, iz, ax, bx, ay, by, az, bz, tmin, c; bool ok; };
-DEV float max3_nn(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-DEV float min3_nn(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 DEV float up32(double x) { x = x < -3.0e38 ? -3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f); }      // >= x
 DEV float down32(double x) { x = x > 3.0e38 ? 3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f); }   // <= x
 DEV BoxFilter make_filter(float M, V3<double> o, V3<double> inv, double t_min, double closest) {
@@ -550,7 +625,7 @@ DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double
             const DBvhNode<double> lf = ld_node_at(P.bvh, leaf);
             double t; uint32_t prim;
             if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
-                range_hit<double, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
+                range_hit<double, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
             if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
             else node = fnode_skip(P, leaf);
         }
@@ -654,7 +729,7 @@ static const uint32_t PRIM_MEDIUM = 0xFFFFFFFFu;
 template <typename T, uint32_t FEATS>
 DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack) {
     if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) return bvh_hit<T, FEATS>(P, ob.geom_first, r, t_min, t_max, t, prim, stack);
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube != 0u);
 }
 
 // One object of the top-level list under HittableList::hit (hit.rs:59-71): offered [t_min, closest], a hit replaces the
@@ -1706,7 +1781,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                         const DBvhNode<T> lf = ld_node_at(P.bvh, leaf);
                         T t; uint32_t prim;
                         if ((!tame || box_inside_tame(lf, r.o, inv, t_min, tv_closest)) &&           // aabb.rs:19-36 on the leaf's own box
-                            range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim)) { tv_closest = t; tv_prim = prim; tv_any = true; F.c = up32(tv_closest); }
+                            range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, r, t_min, tv_closest, t, prim, lf.b == 6u)) { tv_closest = t; tv_prim = prim; tv_any = true; F.c = up32(tv_closest); }
                         tv_node = fnode_skip(P, leaf);
                     }
                     DIAG_ADD(5);

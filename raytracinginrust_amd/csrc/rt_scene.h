@@ -29,6 +29,7 @@ struct HostFlat {             // canonical f64 flattening
     std::vector<DTri<double>> tris;
     std::vector<DBvhNode<double>> bvh;
     std::vector<DFNode> bvh_f;     // f32 companions of bvh[] for the filtered walk (boxes rounded outward; rt_flatten.cpp: make_filter_nodes)
+    float rect_m = 0.0f;           // >= every |coordinate| of every rect; 0: the Cube fast path is off (an inverted Cube or a non-finite rect)
     float filter_m = 0.0f;         // >= every |coordinate| in bvh_f, >= 1; 0: no filter (a box is not finite, inverted, or beyond 2^40)
     std::vector<DMaterial<double>> materials;
     std::vector<DTexture<double>> textures;
