@@ -248,6 +248,12 @@ int rt_debug_bvh_links(rt_scene*, uint32_t* out, uint32_t max_nodes, uint32_t* r
  * ranges of the box steps' conservative f32 filter (rt_kernel.hip: make_filter); bit 4: that filter lets the box through (it must
  * wherever bit 0 is set; it may elsewhere).  Non-zero on a HIP error. */
 int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out);
+/* Test aid: Cube::hit (src/cube.rs:14-36: HittableList::hit over six AARects) on the device for n (cube, ray, [t_min, t_max]) triples
+ * given as host arrays (boxes: min[3] max[3]; rays: origin[3] direction[3]); rect_m as KParams::rect_m (>= every |coordinate|).
+ * out[4 i ..] = t of the six exact rect tests in cube.rs order (NaN: no face accepted), the accepted face (0..5 in cube.rs:17-24 order,
+ * -1), t of the fast path (rt_kernel.hip: cube_fast; NaN: no hit), 8 * clear + (face + 1) of the fast path (clear:
+ * the lane's outcome is outside the approximation's margin — otherwise the kernels run the six tests).  Non-zero on a HIP error. */
+int rt_debug_cube_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, double* out);
 /* Debugging aid for parity work: the hits of ONE camera path, level by level.  rt_debug_trace_path chooses the path (local pixel index =
  * output-order pixel for an unsharded render, sample index; -1 switches it off); the following renders record, per level of ray_color
  * that found a hit, 16 doubles at out[16 * level]: t, position[3], normal[3], front_face, object, primitive kind, primitive index,

@@ -325,12 +325,14 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
 //     closest only ever drops to the exit face's t before the entry face is tried, which is larger: the entry face still wins.
 // Anything not clear — a ray through an edge, a grazing ray, a thin box, a zero or denormal direction component (inf / NaN fail
 // every comparison), t within a few ppm of t_min or closest — makes the WAVE take the six exact tests (range_hit's loop) instead.
-// Returns false when some lane of the wave is not clear (the caller runs the exact loop for everybody; nothing was changed).
 // (KParams::rect_m >= every |coordinate| of every rect — a scene-wide M_a — and is 0 when some Cube has min > max: no fast path then.)
-DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
-    const DRect<double> f0 = ld_rect(P.rects + first);                  // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
-    const double mnz = cl(&P.rects[first + 1u].k);                      // XY face at z = min.z (cube.rs:18)
-    const double mnx = f0.a0, mxx = f0.a1, mny = f0.b0, mxy = f0.b1, mxz = f0.k;
+// WAVE: the kernels' form — false when some lane of the wave is not clear (the caller then runs the six exact tests for everybody;
+// nothing was changed), the exact test only when some lane has a face to test.  !WAVE (the device known-answer test): per lane,
+// `clear_out` says whether this lane's outcome was clear.  face_out in cube.rs:17-24 order.  One function, plain scalars: with the box
+// or the classification in a struct the compiler selects among their fields through an ADDRESS, i.e. puts them in scratch memory.
+template <bool WAVE>
+DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy, double mnz, double mxz, const RayT<double>& ray, double t_min, double t_max,
+                   double& t_out, uint32_t& face_out, bool& any, bool& clear_out) {
     const float rx = __builtin_amdgcn_rcpf((float)ray.d.x), ry = __builtin_amdgcn_rcpf((float)ray.d.y), rz = __builtin_amdgcn_rcpf((float)ray.d.z);
     // the six plane distances, approximately: the exact numerator k - o_k of rect.rs:50, rounded to f32, times the approximate 1 / d_k
     const float ax0 = (float)(mnx - ray.o.x) * rx, ax1 = (float)(mxx - ray.o.x) * rx;
@@ -339,9 +341,9 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
     const float nrx = min_nn(ax0, ax1), frx = max_nn(ax0, ax1), nry = min_nn(ay0, ay1), fry = max_nn(ay0, ay1), nrz = min_nn(az0, az1), frz = max_nn(az0, az1);
     const float s1 = max3_nn(nrx, nry, nrz), s2 = med3_nn(nrx, nry, nrz), e1 = min3_nn(frx, fry, frz), e2 = med3_nn(frx, fry, frz);
     const float RHO = 0x1p-18f;
-    const float A = (0x1p-40f * P.rect_m) * amax3(rx, ry, rz);
+    const float A = (0x1p-40f * rect_m) * amax3(rx, ry, rz);
     const float mu = __builtin_fmaf(RHO, __builtin_fmaxf(amax3(s1, e1, s2), __builtin_fabsf(e2)), A);
-    const bool order_clear = P.rect_m > 0.0f && s1 - s2 > mu && e2 - e1 > mu;
+    const bool order_clear = rect_m > 0.0f && s1 - s2 > mu && e2 - e1 > mu;
     const bool through = e1 - s1 > mu, past = s1 - e1 > mu;              // enters before it leaves: the box is hit / leaves first: it is missed
     // a plane distance against [t_min, t_max], by more than the approximations can be off
     const float lo = __builtin_fmaxf((float)t_min, -1.0e37f), hi = __builtin_fminf((float)t_max, 1.0e37f);
@@ -350,9 +352,10 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
     const bool en_in = s1 - lo > g1 + gl && hi - s1 > g1 + gh, en_out = lo - s1 > g1 + gl || s1 - hi > g1 + gh;
     const bool ex_in = e1 - lo > g2 + gl && hi - e1 > g2 + gh, ex_out = lo - e1 > g2 + gl || e1 - hi > g2 + gh;
     const bool clear = order_clear && (past || (through && (en_in || (en_out && (ex_in || ex_out)))));
-    if (__ballot(!clear) != 0ull) return false;
+    clear_out = clear;
+    if (WAVE ? __ballot(!clear) != 0ull : !clear) return false;
     const bool cand = through && (en_in || ex_in);
-    if (__ballot(cand) == 0ull) return true;                              // nobody's ray has a face to test
+    if (WAVE && __ballot(cand) == 0ull) return true;                      // nobody's ray has a face to test
     if (cand) {
         // which face: the axis of the chosen distance; of that axis' two planes the entry one is min's where d > 0, max's where d < 0
         const bool use_exit = !en_in;
@@ -366,10 +369,18 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
             const bool out_x = px < mnx || px > mxx, out_y = py < mny || py > mxy, out_z = pz < mnz || pz > mxz;      // rect.rs:56-58
             if (!((out_x && !on_x) || (out_y && !on_y) || (out_z && !on_z))) {
                 t_out = t; any = true;
-                prim_out = (G_RECT << 28) | (first + (on_x ? 4u : (on_y ? 2u : 0u)) + (hi_side ? 0u : 1u));            // cube.rs:17-24: (XY, XZ, YZ) x (max, min)
+                face_out = (on_x ? 4u : (on_y ? 2u : 0u)) + (hi_side ? 0u : 1u);                                      // (XY, XZ, YZ) x (max, min)
             }
         }
     }
+    return true;
+}
+DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
+    const DRect<double> f0 = ld_rect(P.rects + first);                  // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
+    const double mnz = cl(&P.rects[first + 1u].k);                      // XY face at z = min.z (cube.rs:18)
+    uint32_t face = 0u; bool hit = false, clear;
+    if (!cube_fast<true>(P.rect_m, f0.a0, f0.a1, f0.b0, f0.b1, mnz, f0.k, ray, t_min, t_max, t_out, face, hit, clear)) return false;
+    if (hit) { any = true; prim_out = (G_RECT << 28) | (first + face); }
     return true;
 }
 
@@ -2100,6 +2111,40 @@ extern "C" int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* 
         hipMemcpy(dt, tlim, n * 16ull, hipMemcpyHostToDevice) == hipSuccess) {
         hipLaunchKernelGGL(rt::aabb_kat_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, n, db, dr, dt, dout);
         if (hipGetLastError() == hipSuccess && hipMemcpy(out, dout, n * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    (void)hipFree(db); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dout);
+    return rc;
+}
+// Known-answer access to the Cube fast path: per case the six exact rect tests in cube.rs order (the reference) and, beside them,
+// what cube_fast says.  out[4 i ..]: t of the six tests (NaN: no face accepted), its face (0..5, -1), t of the fast
+// path (NaN: clear and no hit; only meaningful when clear), 8 * clear + face + 1 of the fast path (face + 1 = 0: no hit).
+namespace rt {
+__global__ void cube_kat_kernel(uint32_t n, float rect_m, const double* boxes, const double* rays, const double* tlim, double* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    struct { double mnx, mny, mnz, mxx, mxy, mxz; } b; b.mnx = boxes[i * 6]; b.mny = boxes[i * 6 + 1]; b.mnz = boxes[i * 6 + 2]; b.mxx = boxes[i * 6 + 3]; b.mxy = boxes[i * 6 + 4]; b.mxz = boxes[i * 6 + 5];
+    RayT<double> ray; ray.o = mk<double>(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]); ray.d = mk<double>(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]); ray.tm = 0.0;
+    const double t_min = tlim[i * 2], t_max = tlim[i * 2 + 1];
+    // the reference: Cube::new's six AARects (cube.rs:17-24) under HittableList::hit
+    DRect<double> f[6] = {{b.mnx, b.mxx, b.mny, b.mxy, b.mxz, 0u, 0u}, {b.mnx, b.mxx, b.mny, b.mxy, b.mnz, 0u, 0u}, {b.mnx, b.mxx, b.mnz, b.mxz, b.mxy, 1u, 0u},
+                          {b.mnx, b.mxx, b.mnz, b.mxz, b.mny, 1u, 0u}, {b.mny, b.mxy, b.mnz, b.mxz, b.mxx, 2u, 0u}, {b.mny, b.mxy, b.mnz, b.mxz, b.mnx, 2u, 0u}};
+    double closest = t_max, t_ref = __builtin_nan(""); int face_ref = -1;
+    for (int k = 0; k < 6; k++) { double t; if (rect_test(f[k], ray, t_min, closest, t)) { closest = t; t_ref = t; face_ref = k; } }
+    double t_fast = __builtin_nan(""); uint32_t face = 0xFFFFFFFFu; bool hit = false, clear = false;
+    { double t; uint32_t fc = 0u; (void)cube_fast<false>(rect_m, b.mnx, b.mxx, b.mny, b.mxy, b.mnz, b.mxz, ray, t_min, t_max, t, fc, hit, clear); if (hit) { t_fast = t; face = fc; } }
+    out[i * 4] = t_ref; out[i * 4 + 1] = (double)face_ref; out[i * 4 + 2] = t_fast; out[i * 4 + 3] = (double)((clear ? 8 : 0) + (int)(face + 1u));
+}
+}
+extern "C" int rt_debug_cube_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, double* out) {
+    if (n == 0) return 0;
+    double *db = nullptr, *dr = nullptr, *dt = nullptr, *dout = nullptr;
+    int rc = -1;
+    if (hipMalloc(&db, n * 48ull) == hipSuccess && hipMalloc(&dr, n * 48ull) == hipSuccess && hipMalloc(&dt, n * 16ull) == hipSuccess &&
+        hipMalloc(&dout, n * 32ull) == hipSuccess &&
+        hipMemcpy(db, boxes, n * 48ull, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dr, rays, n * 48ull, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dt, tlim, n * 16ull, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(rt::cube_kat_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, n, (float)rect_m, db, dr, dt, dout);
+        if (hipGetLastError() == hipSuccess && hipMemcpy(out, dout, n * 32ull, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
     }
     (void)hipFree(db); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dout);
     return rc;

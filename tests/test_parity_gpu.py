@@ -840,6 +840,74 @@ def test_box_filter_is_conservative_on_grazing_rays(pbe):
     assert not culled.any(), f"the f32 filter culled {int(culled.sum())} boxes AABB::hit passes, e.g. case {int(np.flatnonzero(culled)[0])}"
 
 
+def test_cube_fast_path_against_the_six_rect_tests(pbe):
+    """Cube::hit on the device two ways (rt_debug_cube_hit): the reference's six AARect tests in cube.rs:17-24 order under HittableList::hit,
+    and the kernels' fast path (rt_kernel.hip: cube_fast — six approximate plane distances, ONE exact rect test for the face that wins).
+    Wherever the fast path declares a case CLEAR its answer must be the six tests' answer bit for bit: the same t, the same face, or
+    no hit.  Cases aimed at where it could go wrong: rays through points on faces, edges and corners moved by 1e-15 ... 1e-3 of the
+    cube, origins on a face (every bounce off a cube), inside the cube, far away; thin and tiny cubes; cubes far from the origin;
+    [t_min, t_max] ending within ulps of a hit; axis-parallel rays (zero direction components: never clear)."""
+    import ctypes as C
+    rnd = np.random.default_rng(23)
+    n = 600000
+    scale = 10.0 ** rnd.uniform(-1, 4, (n, 1))
+    lo = rnd.uniform(-1, 1, (n, 3)) * scale * rnd.choice([0.0, 1.0, 30.0], (n, 1), p=[0.2, 0.6, 0.2])
+    ext = rnd.uniform(0.05, 1, (n, 3)) * scale
+    thin = rnd.integers(0, 6, n) == 0
+    ext[thin, rnd.integers(0, 3, thin.sum())] *= 10.0 ** rnd.uniform(-7, -2, thin.sum())
+    boxes = np.concatenate([lo, lo + ext], axis=1)
+    w = rnd.choice([0.0, 1.0, 0.5, 0.3], (n, 3), p=[0.3, 0.3, 0.2, 0.2])
+    tgt = lo + w * ext                                                          # on a face / an edge / a corner / inside
+    tgt += rnd.choice([-1.0, 0.0, 1.0], (n, 3)) * 10.0 ** rnd.uniform(-15, -3, (n, 3)) * (np.abs(tgt) + ext)
+    kind = rnd.integers(0, 5, n)
+    o = tgt + rnd.normal(size=(n, 3)) * scale * 10.0 ** rnd.uniform(-2, 1, (n, 1))     # 0, 1: from outside / anywhere
+    on_face = kind == 2                                                         # 2: the origin ON a face (a bounce): leaves outward or inward
+    o[on_face] = (lo + rnd.choice([0.0, 1.0], (n, 3)) * ext)[on_face] * rnd.choice([1.0, 1.0 + 2.0 ** -52, 1.0 - 2.0 ** -52], (on_face.sum(), 3)) \
+        + (rnd.uniform(0, 1, (n, 3)) * ext * (rnd.integers(0, 2, (n, 3))))[on_face] * 0.0
+    k2 = np.flatnonzero(on_face)
+    ax = rnd.integers(0, 3, k2.size)
+    other = rnd.uniform(0, 1, (k2.size, 3)) * ext[k2] + lo[k2]
+    keep = o[k2, ax].copy(); o[k2] = other; o[k2, ax] = keep                    # on the face's plane, somewhere over the face
+    inside = kind == 3
+    o[inside] = (lo + rnd.uniform(0.01, 0.99, (n, 3)) * ext)[inside]
+    d = tgt - o
+    rand_dir = (kind == 2) | (kind == 4)
+    d[rand_dir] = rnd.normal(size=(rand_dir.sum(), 3))
+    d *= 10.0 ** rnd.uniform(-2, 2, (n, 1))
+    axis_par = rnd.integers(0, 40, n) == 0
+    d[axis_par, rnd.integers(0, 3, axis_par.sum())] = 0.0
+    t_hit = np.linalg.norm(tgt - o, axis=1) / np.maximum(np.linalg.norm(d, axis=1), 1e-300)
+    tmax = np.where(rnd.integers(0, 2, n) == 0, np.inf, t_hit * (1.0 + rnd.choice([-4, -1, 0, 1, 4, 1000, 1e6], n) * 2.0 ** -52))
+    tmin = np.where(rnd.integers(0, 4, n) == 0, t_hit * (1.0 + rnd.choice([-4, -1, 0, 1, 4], n) * 2.0 ** -52), 1e-5)
+    tl = np.stack([tmin, tmax], axis=1)
+    rays = np.concatenate([o, d], axis=1)
+    out = np.zeros((n, 4))
+    lib = pbe.lib
+    lib.rt_debug_cube_hit.restype = C.c_int
+    lib.rt_debug_cube_hit.argtypes = [C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    boxes, rays, tl = (np.ascontiguousarray(x, dtype=np.float64) for x in (boxes, rays, tl))
+    rect_m = float(np.abs(boxes).max()) * 1.0000002
+    assert lib.rt_debug_cube_hit(n, rect_m, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, out.ctypes.data) == 0
+    t_ref, face_ref, t_fast, code = out[:, 0], out[:, 1].astype(int), out[:, 2], out[:, 3].astype(int)
+    clear = (code & 8) != 0
+    face_fast = (code & 7) - 1
+    assert clear.sum() > 0.5 * n and (~clear).sum() > 0.02 * n, (int(clear.sum()), n)
+    hit_ref = ~np.isnan(t_ref)
+    assert 0.15 * n < hit_ref.sum() < 0.9 * n
+    assert not clear[axis_par].any()
+    bad = clear & ((face_fast != face_ref) | (t_fast.view(np.uint64) != t_ref.view(np.uint64)) & ~(np.isnan(t_fast) & np.isnan(t_ref)))
+    assert not bad.any(), f"{int(bad.sum())} clear cases differ from the six rect tests, e.g. case {int(np.flatnonzero(bad)[0])}: " \
+                          f"ref (t {t_ref[np.flatnonzero(bad)[0]]!r}, face {face_ref[np.flatnonzero(bad)[0]]}) fast (t {t_fast[np.flatnonzero(bad)[0]]!r}, face {face_fast[np.flatnonzero(bad)[0]]})"
+    # the same cubes with the scene-wide bound far larger than their own coordinates (other rects of the scene): still exact
+    assert lib.rt_debug_cube_hit(n, rect_m * 1000.0, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, out.ctypes.data) == 0
+    clear2 = (out[:, 3].astype(int) & 8) != 0
+    bad2 = clear2 & (((out[:, 3].astype(int) & 7) - 1 != out[:, 1].astype(int)) | (out[:, 2].view(np.uint64) != out[:, 0].view(np.uint64)) & ~(np.isnan(out[:, 2]) & np.isnan(out[:, 0])))
+    assert not bad2.any()
+    # plain rays are (nearly) always clear: the fast path is what runs
+    plain = (kind == 4) & ~axis_par & ~thin & (np.isinf(tmax)) & (tmin == 1e-5)         # a random direction from a random origin
+    assert clear[plain].mean() > 0.99, clear[plain].mean()
+
+
 @pytest.mark.parametrize("name", ["random", "final", "mesh0", "teapot"])
 def test_speculative_box_steps_are_scheduling_only(name, pbe, obe, orc_mod, earth):
     """RT_SPECULATE_BVH: in the lock-step BVH walk a lane that has reached a leaf walks on along the leaf's skip link while it waits for
