@@ -58,8 +58,8 @@
 namespace rt {
 
 // Settled by A/B measurements (docs/history.md names the logs; tools/mkvariant.sh patches a copy of this file for a re-measurement):
-static constexpr int BOX_STEPS = 3;             // box steps per box-or-leaf vote, lock-step BVH loops (round 5, filtered walk: 2 -1 %, 4 +1 %, 6 +2 %)
-static constexpr int BOX_STEPS_PERSIST = 4;     // ... persistent loop (round 5: 3 -2 %, 6 +1.5 %, 8 +2 %)
+static constexpr int BOX_STEPS = 6;             // box steps per box-or-leaf vote, lock-step BVH loops (round 5, filtered walk, against 3: 2 -1 %, 4 +1 %, 6 +2 %)
+static constexpr int BOX_STEPS_PERSIST = 8;     // ... persistent loop (round 5, against 4: 3 -2 %, 6 +1.5 %, 8 +2 %)
 static constexpr uint32_t WW_NUM = 5u, WW_DEN = 8u;       // leaf step once 5/8 of the lanes still in a walk hold a pending leaf (3/8 until round 5)
 static constexpr uint32_t SPEC_NUM = 5u, SPEC_DEN = 8u;   // ... in the walk-ahead form (one-BVH worlds)
 // The kernels are two translation units (RT_TU, above) so that these two code-generation choices can differ between them:
@@ -375,6 +375,10 @@ DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy,
     }
     return true;
 }
+// Which instantiations carry the fast path (a Cube is served by the six exact tests elsewhere — same samples): the list-scene kernels and
+// the all-features BVH kernels.  *Measured* (round 5, profiles/r05_cube_in_bvh_kernels_ab.log): final scene +4 % with it (400 ground boxes
+// as BVH leaves); the mesh kernels and the one-BVH-world kernel, whose scenes have no Cube, lose 1 % to its registers: left out there.
+template <typename T, uint32_t FEATS> struct CubeFast { static constexpr bool on = sizeof(T) == 8u && ((FEATS & F_BVH) == 0u || ((FEATS & F_SPHERES) != 0u && (FEATS & F_SPEC) == 0u)); };
 DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
     const DRect<double> f0 = ld_rect(P.rects + first);                  // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
     const double mnz = cl(&P.rects[first + 1u].k);                      // XY face at z = min.z (cube.rs:18)
@@ -390,7 +394,7 @@ template <typename T, uint32_t FEATS>
 DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false) {
     bool any = false;
     T closest = t_max;
-    if constexpr (sizeof(T) == 8u) {
+    if constexpr (CubeFast<T, FEATS>::on) {
         if (kind == G_RECT && is_cube && cube_hit(P, first, ray, t_min, t_max, closest, prim_out, any)) { t_out = closest; return any; }
     }
     if (kind == G_RECT) {
