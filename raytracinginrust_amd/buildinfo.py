@@ -7,7 +7,7 @@ import hashlib
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-KERNEL_SOURCES = ("rt_kernel.hip", "rt_ir.h", "rt_rng.h", "rt_launch.h", "rt_host.cpp", "rt_scene.h", "Makefile")
+KERNEL_SOURCES = ("rt_kernel.hip", "rt_ir.h", "rt_rng.h", "rt_launch.h", "rt_host.cpp", "rt_scene.h", "rt_flatten.cpp", "Makefile")   # (rt_flatten.cpp since round 5: the filter tree it builds is what the box steps walk)
 
 
 def kernel_source_id() -> str:

@@ -1,0 +1,19 @@
+"""The rows of DESIGN.md §3.1's measured table from the committed profile set of a round.   usage: python tools/roofline_table.py r05"""
+import csv, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+names = {"C1": "`pathtrace_kernel<double, 63 + F_SPEC>` (lock-step, walk-ahead filtered walk, 1024-thread workgroups)", "C2": "`pathtrace_kernel<double, 0>`",
+         "C3": "`pathtrace_kernel<double, 63>`", "C4": "`pathtrace_kernel<double, 261>` (persistent traversal, 768-thread workgroups)", "C5": "`pathtrace_kernel<double, 0>`"}
+for W in ("C1", "C2", "C3", "C4", "C5"):
+    d = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{W}.json")).read())
+    r = d["roofline"]
+    pm = {x["counter"]: x["mean_per_dispatch"] for x in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{W}_pmc_summary.csv")))}
+    f = lambda k: float(pm[k])
+    busy = f("SQ_ACTIVE_INST_VALU") * (f("LAUNCH_WAVES") / 1024) / f("SQ_WAVE_CYCLES"); lanes = f("SQ_THREAD_CYCLES_VALU") / (64 * f("SQ_ACTIVE_INST_VALU"))
+    fetch, write = f("FETCH_SIZE") * 1024 / 1e9, f("WRITE_SIZE") * 1024 / 1e9
+    gbps = (fetch + write) / (r["kernel_ms"] * 1e-3)
+    ks = [x for x in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{W}_kernel_stats.csv"))) if "pathtrace" in x["Name"]][0]
+    print(f"| {W} | {names[W]} | {r['kernel_ms']:.1f} (rocprofv3: {float(ks['AverageNs']) / 1e6:.1f} avg, {float(ks['MaxNs']) / 1e6:.1f} max over {ks['Calls']} launches) | {d['value']:.0f} | {r['achieved']:.1f} | "
+          f"**{r['frac']:.3f}** ({r['frac_of_measured_issue']:.2f}); unweighted {r['frac_unweighted']:.3f} | {busy:.2f} × {lanes:.2f} = {busy * lanes:.2f} | {fetch:.3f} + {write:.2f} GB | "
+          f"{gbps:.1f} GB/s = {gbps / 8000 * 100:.2f} % | {r['model_hbm']['ratio']:.2f}{' (flagged)' if r['model_hbm']['exceeds_hbm_peak'] else ''} |")
+    print(f"    VALU wave-instructions per sample {f('SQ_INSTS_VALU') / r['samples_per_launch']:.1f}, kernel_source_id {pm['kernel_source_id']}", file=sys.stderr)
