@@ -46,8 +46,9 @@ enum {
                               still resolved by the reference's DFS order.  Can differ only where a last-ulp box cull depends
                               on the order hits are found.                                                                   */
     RT_PERSISTENT_BVH = 16, /* scheduling only, same samples: lanes keep their place inside a BVH while the rest of the wavefront
-                              shades / regenerates (mesh kernels).  Chosen automatically for a triangle-mesh BVH that stands
-                              beside other top-level objects (most rays never enter it); this flag forces it on ...            */
+                              shades / regenerates (mesh kernels).  Chosen automatically for triangle-mesh BVHs that stand
+                              beside other top-level objects: by tree size, or — frames of >= 2^28 samples — by timing both loops
+                              on a small copy of the view at the scene's first render; this flag forces it on ...            */
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
@@ -242,6 +243,12 @@ int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
  * c = left child; skip = the node BVH::hit's recursion (src/bvh.rs:77-91) reaches next once this node's subtree is finished or culled
  * (0xFFFFFFFF: the search is over).  roots_out: root node of every BVH object of the world list.  Returns the node count or -1. */
 int rt_debug_bvh_links(rt_scene*, uint32_t* out, uint32_t max_nodes, uint32_t* roots_out, uint32_t max_roots, uint32_t* n_roots_out);
+/* Test aid (host only, no GPU): the filter tree the f64 kernels' box steps walk — the f32 companion of every node of the tree above
+ * (same ids): boxes6_out[6 i ..] = {min.x, max.x, min.y, max.y, min.z, max.z} rounded OUTWARD to f32, links2_out[2 i ..] = {skip, info}
+ * (info: the first child, or for a leaf its own id | 0x40000000; near-duplicate inner nodes have been taken out of these links),
+ * f64_boxes_out[6 i ..] = the exact box {min[3], max[3]}; *filter_m_out >= every |coordinate| of the f32 boxes (0: filter off).
+ * Any of the output pointers may be NULL.  Returns the node count or -1. */
+int rt_debug_filter_nodes(rt_scene*, float* boxes6_out, uint32_t* links2_out, double* f64_boxes_out, uint32_t max_nodes, float* filter_m_out);
 /* Test aid: AABB::hit (src/aabb.rs:19-36) evaluated on the device for n (box, ray, [t_min, t_max]) triples given as host arrays
  * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
  * leaf steps use for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300); bit 3: ray and box are inside the

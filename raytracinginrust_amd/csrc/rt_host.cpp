@@ -352,6 +352,23 @@ int rt_debug_bvh_links(rt_scene* sc, uint32_t* out, uint32_t max_nodes, uint32_t
     return (int)f.bvh.size();
 }
 
+// Test aid (host only): the filter tree the f64 kernels' box steps walk (rt_ir.h DFNode, rt_flatten.cpp make_filter_nodes), node for
+// node beside rt_debug_bvh_links' f64 tree: boxes6_out[6*i ..] = {min.x, max.x, min.y, max.y, min.z, max.z} rounded outward to f32,
+// links2_out[2*i ..] = {skip, info} (info: first child, or own id | 0x40000000 for a leaf), f64_boxes_out[6*i ..] = the exact box
+// {min[3], max[3]}.  *filter_m_out = KParams::filter_m.  Returns the number of nodes, or -1.
+int rt_debug_filter_nodes(rt_scene* sc, float* boxes6_out, uint32_t* links2_out, double* f64_boxes_out, uint32_t max_nodes, float* filter_m_out) {
+    if (!sc) return -1;
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    const HostFlat& f = sc->s.flat;
+    for (size_t i = 0; i < f.bvh_f.size() && i < max_nodes; i++) {
+        if (boxes6_out) for (int k = 0; k < 6; k++) boxes6_out[6 * i + k] = f.bvh_f[i].b[k];
+        if (links2_out) { links2_out[2 * i] = f.bvh_f[i].skip; links2_out[2 * i + 1] = f.bvh_f[i].info; }
+        if (f64_boxes_out) for (int k = 0; k < 3; k++) { f64_boxes_out[6 * i + k] = f.bvh[i].mn[k]; f64_boxes_out[6 * i + 3 + k] = f.bvh[i].mx[k]; }
+    }
+    if (filter_m_out) *filter_m_out = f.filter_m;
+    return (int)f.bvh_f.size();
+}
+
 uint32_t rt_local_tiles(uint32_t W, uint32_t H, uint32_t tile_px, uint32_t rank, uint32_t world) {
     (void)rank;
     if (tile_px == 0 || world == 0) return 0;
@@ -496,16 +513,26 @@ static int acquire_slot(Scene& s, Scene::DeviceCtx& c, hipStream_t stream, Scene
 // LDS traversal stack entries per lane: none in the reference's left-then-right order (skip links, rt_ir.h DBvhNode), the tree's depth
 // when children are visited nearer-first
 static uint32_t stack_depth_of(const HostFlat& f, uint32_t effective) { return ((effective & RT_NEAR_FIRST_BVH) && (f.feats & F_BVH)) ? f.bvh_depth : 0u; }
-static uint32_t effective_flags(const HostFlat& f, uint32_t flags) {
+// A mesh scene whose loop shape is open: triangle-mesh BVHs beside other top-level objects, neither loop asked for.
+static bool loop_shape_is_open(const HostFlat& f, uint32_t flags, size_t* n_bvh_objects_out = nullptr) {
+    if ((flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) || !(f.feats & F_BVH) || (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u) return false;
+    size_t n_bvh_objects = 0;
+    for (const DObject& ob : f.objects) n_bvh_objects += ob.geom_kind == G_BVH ? 1u : 0u;
+    if (n_bvh_objects_out) *n_bvh_objects_out = n_bvh_objects;
+    return n_bvh_objects != 0 && n_bvh_objects < f.objects.size();
+}
+static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choice = -1) {
     uint32_t out = flags;
-    if (!(flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) && (f.feats & F_BVH) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) == 0u) {
-        size_t n_bvh_objects = 0;
-        for (const DObject& ob : f.objects) n_bvh_objects += ob.geom_kind == G_BVH ? 1u : 0u;
-        // ... and only for trees of some size: *measured* (round 4, tools/mesh_size_probe.py: a lit room with one / two random triangle
-        // meshes, persistent vs lock-step ms) one tree of 63 / 199 / 599 / 1999 / 5999 nodes 1.24 / 1.09 / 0.99 / 0.85 / 0.80, two trees of
-        // 126 / 398 / 1198 / 3998 / 11998 nodes in all 1.73 / 1.28 / 1.14 / 1.02 / 0.86 — the pass machinery costs more than the waiting it
-        // removes while a walk is a few dozen steps.  The teapot room (one tree, 2047 nodes) keeps the persistent loop.
-        if (n_bvh_objects != 0 && n_bvh_objects < f.objects.size() && f.bvh.size() >= 640u * n_bvh_objects * n_bvh_objects) out |= RT_PERSISTENT_BVH;
+    size_t n_bvh_objects = 0;
+    if (loop_shape_is_open(f, flags, &n_bvh_objects)) {
+        // Measured for this scene and view where a frame is big enough to be worth two small calibration launches (calibrate_loop_shape);
+        // otherwise by tree size: *measured* (tools/mesh_size_probe.py: a lit room with one / two random triangle meshes, persistent ÷
+        // lock-step kernel time; round 4 / round 5 with the filtered walk) one tree of 63 / 199 / 599 / 1999 / 5999 nodes 1.24 / 1.09 / 0.99 /
+        // 0.85 / 0.80 then, 1.26 / 1.18 / 1.13 / 1.10 / 0.95 now; two trees of 126 ... 11998 nodes 1.73 ... 0.86 then, 1.82 ... 1.05 now —
+        // while the teapot room (one tree, 2047 nodes, a closed surface that fills a third of the view) is 0.85 then and 0.90 now: node
+        // counts alone do not decide it, which is why it is measured where it matters.
+        const bool by_size = f.bvh.size() >= 640u * n_bvh_objects * n_bvh_objects;
+        if (loop_choice >= 0 ? loop_choice == 1 : by_size) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
@@ -571,7 +598,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         P.cam.cu[k] = (T)cam.cu[k]; P.cam.cv[k] = (T)cam.cv[k]; P.background[k] = (T)bg[k];
     }
     P.cam.lens_radius = (T)cam.lens_radius; P.cam.time0 = (T)cam.time0; P.cam.time1 = (T)cam.time1;
-    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = effective_flags(f, flags);
+    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = effective_flags(f, flags, s.loop_choice);
     P.stack_depth = stack_depth_of(f, P.flags);
     P.tile_px = tile_px; P.rank = rank; P.world = world;
     P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
@@ -673,6 +700,45 @@ int check_frame_args(rt_scene* sc, const rt_camera* cam, const double* bg, uint3
     return 0;
 }
 
+// Mesh scenes: which loop shape is faster depends on what the rays of THIS view do inside the trees (a closed surface that fills a third
+// of the frame: the persistent loop by 10 %; a sparse cloud of triangles in a corner: the lock-step loop by 10 ... 80 %), not on anything
+// the flattener can see.  Both give the same samples bit for bit, so the first render of a frame that is worth it (>= 2^28 samples) first
+// renders the same view at <= 1024 x 1024 x 16 twice in each shape, on the caller's stream, and keeps the faster one for the scene
+// (Scene::loop_choice; forgotten when the scene changes).  Within 3 % of each other the size rule stands.  The calibration launches do
+// not count in rt_kernel_time_total and leave no trace in rt_last_* (the render that follows overwrites them).
+static int calibrate_loop_shape(Scene& s, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                                uint64_t seed, uint32_t flags, hipStream_t stream) {
+    if (s.loop_choice >= 0 || !loop_shape_is_open(s.flat, flags) || (flags & RT_NEAR_FIRST_BVH) || (uint64_t)W * H * spp < (1ull << 28)) return 0;
+    if (std::getenv("RT_NO_LOOP_CALIBRATION")) return 0;                   // A/B runs and tests of the size rule
+    // (the copies must be far above the ~0.5 ms a persistent launch spends filling and draining the chip, and long enough for the loops'
+    // steady state: *measured* on the teapot room, persistent ÷ lock-step 1.05 at 4 M samples, 0.94 at 20 M, 0.92 at 41 M, 0.85 at 4 G)
+    uint32_t k = 1; while ((uint64_t)(W / k) * (H / k) > 1048576ull) k++;
+    const uint32_t Wc = std::max(2u, W / k), Hc = std::max(2u, H / k), sc_spp = std::min(spp, 16u);
+    void* d_tmp = nullptr;
+    const size_t bytes = (size_t)Wc * Hc * 3 * sizeof(double);
+    HIP_OK(hipMalloc(&d_tmp, bytes));
+    if (settle_all_launches(s)) { (void)hipFree(d_tmp); return -1; }
+    const double keep_ms = s.kernel_ms_total; const unsigned long long keep_n = s.kernel_launches_timed;
+    float best[2] = {1e30f, 1e30f};
+    int rc = 0, dev = 0; (void)hipGetDevice(&dev);
+    for (int round = 0; round < 2 && rc == 0; round++)
+        for (int shape = 0; shape < 2 && rc == 0; shape++) {
+            const uint32_t fl = flags | (shape ? RT_PERSISTENT_BVH : RT_LOCKSTEP_BVH);
+            rc = (flags & RT_F32) ? render_impl<float>(s, cam, bg, Wc, Hc, sc_spp, max_depth, seed, fl, Wc * Hc, 0, 1, d_tmp, bytes, nullptr, stream)
+                                  : render_impl<double>(s, cam, bg, Wc, Hc, sc_spp, max_depth, seed, fl, Wc * Hc, 0, 1, d_tmp, bytes, nullptr, stream);
+            float ms = 0.f;
+            if (rc == 0 && device_kernel_ms(s, dev, &ms) == 0) best[shape] = std::min(best[shape], ms); else rc = -1;
+        }
+    if (settle_all_launches(s)) rc = -1;
+    s.kernel_ms_total = keep_ms; s.kernel_launches_timed = keep_n;
+    (void)hipFree(d_tmp);
+    if (rc != 0) return -1;
+    if (best[1] < 0.97f * best[0]) s.loop_choice = 1;
+    else if (best[0] < 0.97f * best[1]) s.loop_choice = 0;
+    else s.loop_choice = (effective_flags(s.flat, flags, -1) & RT_PERSISTENT_BVH) ? 1 : 0;
+    return 0;
+}
+
 int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
                void* d_samples, hipStream_t stream) {
@@ -680,6 +746,7 @@ int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t 
     if (tile_px == 0 || world == 0 || rank >= world) return set_err("bad tile decomposition");
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    if (calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, stream)) return -1;
     if (flags & RT_F32) return render_impl<float>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
     return render_impl<double>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
 }
@@ -717,7 +784,7 @@ int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
         if (!l.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_start = e; }
         if (!l.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_stop = e; }
     }
-    const uint32_t eff = effective_flags(s.flat, flags);
+    const uint32_t eff = effective_flags(s.flat, flags, s.loop_choice);
     const LaunchShape shape = pathtrace_shape(s.flat.feats, eff);
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     int bpc;

@@ -57,6 +57,8 @@ struct Scene {
     int world = -1;
     unsigned trav_hi = 56, trav_lo = 16, trav_leaf = 32;      // persistent-traversal schedule (rt_scene_set_traversal_schedule); measured best on the teapot room (round 5, the filtered walk: profiles/r05_trav_schedule_sweep.log; 40 / 24 / 24 before)
     int bvh_builder = 0;      // 0: the reference's widest-axis object-median split (bvh.rs:18-73); 1: binned SAH (opt-in)
+    int loop_choice = -1;     // mesh scenes: which loop shape a calibration render found faster for THIS scene and view (1 persistent traversal,
+                              // 0 lock-step; -1 not measured: the size rule decides) — rt_host.cpp: calibrate_loop_shape; same samples either way
     std::vector<int> lights;
     std::string error;
 
@@ -115,7 +117,7 @@ struct Scene {
     // debugging aid (rt_debug_trace_path; -DRT_TRACE_PATH builds of the kernels): the path whose hits are recorded, and the device buffer
     long long trace_px = -1, trace_s = -1; void* d_trace = nullptr; int trace_device = -1; uint32_t trace_levels = 0;     // trace_levels: 16-double records d_trace holds
 
-    void invalidate() { flat_valid = false; }
+    void invalidate() { flat_valid = false; loop_choice = -1; }
     DeviceCtx& ctx_for(int device) {
         for (DeviceCtx* c : ctxs) if (c->device == device) return *c;
         DeviceCtx* c = new DeviceCtx(); c->device = device; ctxs.push_back(c); return *c;

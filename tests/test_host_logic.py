@@ -283,6 +283,57 @@ def test_bvh_skip_links_thread_the_recursions_order(name, pbe, earth):
     assert seen.all()                                             # every node belongs to exactly the trees walked
 
 
+@pytest.mark.parametrize("name", ["random", "final", "teapot"])
+def test_filter_tree_is_a_conservative_hierarchy_over_the_same_leaves(name, pbe, earth):
+    """The f64 kernels' box steps walk the FILTER tree (rt_ir.h DFNode; rt_flatten.cpp make_filter_nodes): f32 boxes and links from which
+    near-duplicate inner nodes have been taken out.  What makes that exact (rt_kernel.hip: the ordered-scan form of BVH::hit) is checked
+    here on the host: (1) every f32 box contains its node's f64 box (outward rounding) and filter_m bounds every coordinate; (2) with every
+    box test passing the filter walk meets exactly the leaves of the reference tree, each once, in the reference's depth-first order;
+    (3) every node the filter walk can stand at contains every leaf it reaches before that node's skip link — culling a node never
+    skips a leaf outside it; (4) contraction did take nodes out (and never a leaf or a root)."""
+    b, _, _ = build_scene(name, pbe, earth)
+    n = R.flatten(b)["bvh_nodes"]
+    links = (C.c_uint32 * (4 * n))(); roots = (C.c_uint32 * 8)(); n_roots = C.c_uint32(0)
+    assert pbe.lib.rt_debug_bvh_links(b.h, links, n, roots, 8, C.byref(n_roots)) == n
+    L = np.frombuffer(links, np.uint32).reshape(n, 4)
+    fb = np.zeros((n, 6), np.float32); fl = np.zeros((n, 2), np.uint32); eb = np.zeros((n, 6)); fm = C.c_float(0)
+    pbe.lib.rt_debug_filter_nodes.restype = C.c_int
+    pbe.lib.rt_debug_filter_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    assert pbe.lib.rt_debug_filter_nodes(b.h, fb.ctypes.data, fl.ctypes.data, eb.ctypes.data, n, C.byref(fm)) == n
+    LEAF, FLEAF, DONE = 1 << 31, 0x40000000, 0xFFFFFFFF
+    # (1)
+    assert (fb[:, 0::2].astype(np.float64) <= eb[:, :3]).all() and (fb[:, 1::2].astype(np.float64) >= eb[:, 3:]).all()
+    assert fm.value >= max(1.0, float(np.abs(fb).max())) and fm.value <= 2.0 ** 40
+    is_leaf = (L[:, 0] & LEAF) != 0
+    assert np.array_equal((fl[:, 1] & FLEAF) != 0, is_leaf) and np.array_equal(fl[is_leaf, 1] & ~np.uint32(FLEAF), np.flatnonzero(is_leaf).astype(np.uint32))
+    visited_inner = set()
+    for root in list(roots)[:n_roots.value]:
+        want = []                                                  # the reference's leaves in depth-first order (bvh.rs:77-91)
+        todo = [int(root)]
+        while todo:
+            i = todo.pop()
+            if L[i, 0] & LEAF: want.append(i)
+            else: todo.append(int(L[i, 1])); todo.append(int(L[i, 2]))
+        got, path, i = [], [], int(root)                           # (2) the filter walk, every test passing
+        while i != DONE:
+            path.append(i)
+            if fl[i, 1] & FLEAF: got.append(i); i = int(fl[i, 0])
+            else: visited_inner.add(i); i = int(fl[i, 1])
+            assert len(path) <= 2 * n
+        assert got == want and fl[root, 0] == DONE
+        # (3) the leaves met between standing at node x and arriving at x's skip link all lie inside x's box
+        pos = {x: k for k, x in enumerate(path)}
+        for x in path:
+            end = pos.get(int(fl[x, 0]), len(path)) if fl[x, 0] != DONE else len(path)
+            below = [y for y in path[pos[x]:end] if fl[y, 1] & FLEAF]
+            assert below, x
+            bb = eb[below]
+            assert (bb[:, :3].min(axis=0) >= fb[x, 0::2]).all() and (bb[:, 3:].max(axis=0) <= fb[x, 1::2]).all(), x
+    # (4)
+    n_inner = int((~is_leaf).sum())
+    assert 0 < n_inner - len(visited_inner) < n_inner // 2, (n_inner, len(visited_inner))
+
+
 def test_valu_op_weights_follow_from_the_committed_ubench_run():
     """The issue weights of the f64-VALU roofline (workloads.VALU_OP_WEIGHTS) are nothing but arithmetic on profiles/r04_ubench.csv, the
     tools/ubench output of the MI355X: a reader can recompute `roofline.frac` from files in the repository alone."""

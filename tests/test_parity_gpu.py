@@ -756,6 +756,61 @@ def test_aabb_hit_on_the_device_against_the_oracle(pbe, obe):
     assert extra <= 0.001 * plain.sum(), f"the f32 filter passes {extra} boxes of {plain.sum()} that AABB::hit culls"
 
 
+def _cloud_room(be, n_tris, radius):
+    """A lit room with ONE sparse cloud of small triangles in a corner (tools/mesh_size_probe.py's family)."""
+    rs = np.random.RandomState(n_tris)
+    b = SceneBuilder(be)
+    white = b.Lambertian(b.ConstantTexture((0.73, 0.73, 0.73)))
+    light = b.DiffuseLight(b.ConstantTexture((12.0, 12.0, 12.0)))
+    world = b.HittableList()
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, 150.0, 400.0, 150.0, 400.0, 554.0, light))
+    world.push(lamp)
+    world.push(b.AARect(Plane.XZ, 0.0, 555.0, 0.0, 555.0, 0.0, white))
+    world.push(b.AARect(Plane.XY, 0.0, 555.0, 0.0, 555.0, 555.0, white))
+    tris = []
+    for _ in range(n_tris):
+        p0 = np.array([200.0, 120.0, 250.0]) + rs.uniform(-radius, radius, 3)
+        tris.append(b.Triangle([tuple(p0), tuple(p0 + rs.uniform(-8, 8, 3)), tuple(p0 + rs.uniform(-8, 8, 3))], white))
+    world.push(b.BVH(tris, 0.0, 1.0))
+    b.set_scene(world, [lamp])
+    return b, Camera((278.0, 278.0, -800.0), (278.0, 278.0, 0.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0), (0.02, 0.02, 0.03)
+
+
+def test_loop_shape_of_a_mesh_scene_is_measured(pbe, monkeypatch):
+    """Mesh scenes run a persistent-traversal or a lock-step loop — same samples, and which is faster depends on the view, not on the
+    tree's size (round 5: the teapot room's 2047-node tree prefers the persistent loop by 10 %, a 1999-node cloud of triangles the
+    lock-step loop by 10 %).  The first render of a frame of >= 2^28 samples measures both on a smaller copy of the view and keeps the
+    faster (rt_host.cpp: calibrate_loop_shape); small frames and RT_NO_LOOP_CALIBRATION keep the size rule."""
+    W, H, spp, depth = 1024, 1024, 256, 50
+    for make in (lambda: scenes.cornell_test(pbe, scenes.asset_path("teapot.obj")), lambda: _cloud_room(pbe, 1000, 70.0)):
+        b, cam, bg = make()
+        t = {}
+        for name, fl in (("lock", R.RT_LOCKSTEP_BVH), ("pers", R.RT_PERSISTENT_BVH)):
+            ms = []
+            for _ in range(3):
+                R.render(b, cam, bg, W, H, spp, depth, flags=fl); ms.append(R.last_kernel_ms(b))
+            t[name] = min(ms)
+        b2, cam2, bg2 = make()                                     # a fresh scene: nothing measured yet
+        _, auto = R.render(b2, cam2, bg2, 96, 96, 4, depth, want_samples=True)            # a small frame first: no calibration, the size rule (persistent: >= 640 nodes)
+        assert R.last_traversal_stats(b2)["traversal_steps"] > 0
+        ms = []
+        for _ in range(3):
+            R.render(b2, cam2, bg2, W, H, spp, depth); ms.append(R.last_kernel_ms(b2))
+        chose_pers = R.last_traversal_stats(b2)["traversal_steps"] > 0
+        assert min(ms) <= 1.04 * min(t.values()), (t, ms)
+        if abs(t["pers"] - t["lock"]) > 0.06 * min(t.values()):
+            assert chose_pers == (t["pers"] < t["lock"]), (t, chose_pers)
+        total_ms, n = R.kernel_time_total(b2)
+        assert n == 4                                               # the calibration launches are not in the caller's totals
+        _, lock = R.render(b2, cam2, bg2, 96, 96, 4, depth, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
+        assert np.array_equal(auto.view(np.uint64), lock.view(np.uint64))
+        monkeypatch.setenv("RT_NO_LOOP_CALIBRATION", "1")
+        b3, cam3, bg3 = make()
+        R.render(b3, cam3, bg3, W, H, spp, depth)
+        assert R.last_traversal_stats(b3)["traversal_steps"] > 0    # the size rule: 1999 / 2047 nodes >= 640
+        monkeypatch.delenv("RT_NO_LOOP_CALIBRATION")
+
+
 def _big_mesh_room(be, n_tris):
     rs = np.random.RandomState(5)
     b = SceneBuilder(be)
