@@ -47,7 +47,7 @@ enum {
                               on the order hits are found.                                                                   */
     RT_PERSISTENT_BVH = 16, /* scheduling only, same samples: lanes keep their place inside a BVH while the rest of the wavefront
                               shades / regenerates (mesh kernels).  Chosen automatically for triangle-mesh BVHs that stand
-                              beside other top-level objects: by tree size, or — frames of >= 2^28 samples — by timing both loops
+                              beside other top-level objects: by tree size, or — frames of >= 1e8 samples — by timing both loops
                               on a small copy of the view at the scene's first render; this flag forces it on ...            */
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then

@@ -702,13 +702,13 @@ int check_frame_args(rt_scene* sc, const rt_camera* cam, const double* bg, uint3
 
 // Mesh scenes: which loop shape is faster depends on what the rays of THIS view do inside the trees (a closed surface that fills a third
 // of the frame: the persistent loop by 10 %; a sparse cloud of triangles in a corner: the lock-step loop by 10 ... 80 %), not on anything
-// the flattener can see.  Both give the same samples bit for bit, so the first render of a frame that is worth it (>= 2^28 samples) first
+// the flattener can see.  Both give the same samples bit for bit, so the first render of a frame that is worth it (>= 1e8 samples) first
 // renders the same view at <= 1024 x 1024 x 16 twice in each shape, on the caller's stream, and keeps the faster one for the scene
 // (Scene::loop_choice; forgotten when the scene changes).  Within 3 % of each other the size rule stands.  The calibration launches do
 // not count in rt_kernel_time_total and leave no trace in rt_last_* (the render that follows overwrites them).
 static int calibrate_loop_shape(Scene& s, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                                 uint64_t seed, uint32_t flags, hipStream_t stream) {
-    if (s.loop_choice >= 0 || !loop_shape_is_open(s.flat, flags) || (flags & RT_NEAR_FIRST_BVH) || (uint64_t)W * H * spp < (1ull << 28)) return 0;
+    if (s.loop_choice >= 0 || !loop_shape_is_open(s.flat, flags) || (flags & RT_NEAR_FIRST_BVH) || (uint64_t)W * H * spp < 100000000ull) return 0;
     if (std::getenv("RT_NO_LOOP_CALIBRATION")) return 0;                   // A/B runs and tests of the size rule
     // (the copies must be far above the ~0.5 ms a persistent launch spends filling and draining the chip, and long enough for the loops'
     // steady state: *measured* on the teapot room, persistent ÷ lock-step 1.05 at 4 M samples, 0.94 at 20 M, 0.92 at 41 M, 0.85 at 4 G)

@@ -779,7 +779,7 @@ def _cloud_room(be, n_tris, radius):
 def test_loop_shape_of_a_mesh_scene_is_measured(pbe, monkeypatch):
     """Mesh scenes run a persistent-traversal or a lock-step loop — same samples, and which is faster depends on the view, not on the
     tree's size (round 5: the teapot room's 2047-node tree prefers the persistent loop by 10 %, a 1999-node cloud of triangles the
-    lock-step loop by 10 %).  The first render of a frame of >= 2^28 samples measures both on a smaller copy of the view and keeps the
+    lock-step loop by 10 %).  The first render of a frame of >= 1e8 samples measures both on a smaller copy of the view and keeps the
     faster (rt_host.cpp: calibrate_loop_shape); small frames and RT_NO_LOOP_CALIBRATION keep the size rule."""
     W, H, spp, depth = 1024, 1024, 256, 50
     for make in (lambda: scenes.cornell_test(pbe, scenes.asset_path("teapot.obj")), lambda: _cloud_room(pbe, 1000, 70.0)):
