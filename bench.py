@@ -139,6 +139,8 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
             "peak_measured_issue": workloads.F64_VALU_MEASURED_ISSUE_OPS / 1e12, "frac_of_measured_issue": achieved / (workloads.F64_VALU_MEASURED_ISSUE_OPS / 1e12),
             "traffic": None, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, KB counters x 1024; raw values)",
             "traffic_source": None, "hbm_measured_GBps": None, "hbm_measured_frac": None,
+            "achieved_counts": "the reference's ALGORITHMIC f64 operations per sample x samples / kernel time; since round 5 the kernels execute fewer than that "
+                               "(inner BVH boxes by an f32 filter, one exact rect test per Cube instead of six) — what is really issued is `valu_pmc`",
             "ops_per_sample": ops, "flops_per_sample_unweighted": workloads.flops(per_kind),
             "achieved_unweighted_TFLOPs": workloads.flops(per_kind) * local_samples / (k_ms * 1e-3) / 1e12,
             # the same kernel time priced WITHOUT issue weights, against the chip's f64 vector specification (78.6 TFLOP/s counts an FMA
