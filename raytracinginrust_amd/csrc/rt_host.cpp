@@ -719,6 +719,8 @@ static int calibrate_loop_shape(Scene& s, const rt_camera* cam, const double bg[
     HIP_OK(hipMalloc(&d_tmp, bytes));
     if (settle_all_launches(s)) { (void)hipFree(d_tmp); return -1; }
     const double keep_ms = s.kernel_ms_total; const unsigned long long keep_n = s.kernel_launches_timed;
+    // (inside an rt_render_multi* frame the N launches share one frame number: the calibration launches get their own, and the frame a fresh one)
+    const bool in_group = s.group_open; s.group_open = false;
     float best[2] = {1e30f, 1e30f};
     int rc = 0, dev = 0; (void)hipGetDevice(&dev);
     for (int round = 0; round < 2 && rc == 0; round++)
@@ -731,6 +733,7 @@ static int calibrate_loop_shape(Scene& s, const rt_camera* cam, const double bg[
         }
     if (settle_all_launches(s)) rc = -1;
     s.kernel_ms_total = keep_ms; s.kernel_launches_timed = keep_n;
+    s.group_open = in_group; if (in_group) s.frame_group++;
     (void)hipFree(d_tmp);
     if (rc != 0) return -1;
     if (best[1] < 0.97f * best[0]) s.loop_choice = 1;

@@ -155,6 +155,25 @@ def test_last_multi_ranks_reports_every_rank(pbe, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_loop_calibration_stays_out_of_a_multi_frames_counters(pbe, monkeypatch):
+    """A large mesh frame measures its loop shape with four small launches at the scene's first render (rt_host.cpp: calibrate_loop_shape).
+    Inside an rt_render_multi frame — whose N launches share one frame number so that rt_last_stats can sum them — those launches must
+    not be counted: the frame's counters equal a plain single-launch render's."""
+    from test_parity_gpu import _cloud_room
+    W, H, spp, depth = 1024, 1024, 100, 20
+    b, cam, bg = _cloud_room(pbe, 400, 70.0)
+    ref = R.render(b, cam, bg, W, H, spp, depth)
+    want = R.last_stats(b)
+    b2, cam2, bg2 = _cloud_room(pbe, 400, 70.0)                    # a fresh scene: its first render is the multi frame
+    monkeypatch.setenv("RT_MULTI_VIRTUAL_RANKS", "2")
+    got = R.render_multi(b2, cam2, bg2, W, H, spp, depth, device_mask=1)
+    monkeypatch.delenv("RT_MULTI_VIRTUAL_RANKS")
+    st = R.last_stats(b2)
+    assert np.all(np.abs(got - ref) <= 1e-12 * (spp + np.abs(ref)))
+    assert st["live_lane_iterations"] == want["live_lane_iterations"] and st["nonfinite_samples"] == want["nonfinite_samples"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("gpus", [2, 8])
 def test_bench_runs_in_process_without_a_launcher(gpus):
     """`python bench.py --gpus N` with no launcher (what the driver's SCALE run may use): the in-process mode through
