@@ -162,7 +162,7 @@ def test_random_scene_parity(pbe, obe, earth, seed):
 def _rand_list_scene(be, seed):
     """A list scene (no BVH, no sphere, constant textures, Lambertian / Metal / DiffuseLight): what the lean kernels serve — their
     straight-line paths for wrapper-less objects and for `Translate(RotateY(..))`, the generic wrapper loops for every other chain,
-    the merged Lambertian / Metal arms with 0, 1 or 2 lights.  (rt_kernel.hip: RT_LEAN_STRAIGHT, RT_MERGE_ARMS.)"""
+    the merged Lambertian / Metal arms with 0, 1 or 2 lights.  (rt_kernel.hip: object_hit / finalize_hit's FEATS == 0 blocks, MERGE_ARMS; since round 5 also the Cube fast path, cube_fast.)"""
     rs = np.random.RandomState(9000 + seed)
     b = SceneBuilder(be)
 

@@ -251,7 +251,7 @@ def test_jpeg_restart_intervals(tmp_path):
 
 @pytest.mark.parametrize("name", ["random", "final", "teapot"])
 def test_bvh_skip_links_thread_the_recursions_order(name, pbe, earth):
-    """The kernels walk a BVH in the reference's order without a stack: `node = hit && inner ? left : skip` (rt_kernel.hip bvh_hit_ww).
+    """The kernels walk a BVH in the reference's order without a stack: `node = hit && inner ? left : skip` (rt_kernel.hip bvh_hit_ww; the f64 kernels' filtered walk threads the same links, bvh_hit_filt).
     For ANY pattern of box-test outcomes that walk must meet the nodes BVH::hit's recursion meets (src/bvh.rs:77-91: bbox, left, right),
     in the same order.  Checked on the flattened trees of the shipped scenes with all-hit, all-miss and random outcome patterns."""
     be = pbe

@@ -967,7 +967,8 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe):
 def test_speculative_box_steps_are_scheduling_only(name, pbe, obe, orc_mod, earth):
     """RT_SPECULATE_BVH: in the lock-step BVH walk a lane that has reached a leaf walks on along the leaf's skip link while it waits for
     the leaf step, holds at most two leaves, and a leaf reached past an untested one is re-tested against its own box with the closest hit
-    as it is when its turn comes (rt_kernel.hip: bvh_hit_spec; exact by containment of a child's slab interval in its ancestors').
+    as it is when its turn comes (rt_kernel.hip: bvh_hit_filt<.., SPEC>; exact by containment of a child's slab interval in its ancestors' —
+    since round 5 EVERY leaf is re-tested against its own box in the leaf step, which is what makes walking ahead free).
     Chosen automatically when the world is ONE BVH (random spheres); forced on here for the others.  Every sample is bit-identical to the
     plain walk and matches the oracle."""
     mk = (lambda be: _mesh_room(be, 0)) if name == "mesh0" else (lambda be: build_scene(name, be, earth))
