@@ -243,7 +243,7 @@ int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
  * c = left child; skip = the node BVH::hit's recursion (src/bvh.rs:77-91) reaches next once this node's subtree is finished or culled
  * (0xFFFFFFFF: the search is over).  roots_out: root node of every BVH object of the world list.  Returns the node count or -1. */
 int rt_debug_bvh_links(rt_scene*, uint32_t* out, uint32_t max_nodes, uint32_t* roots_out, uint32_t max_roots, uint32_t* n_roots_out);
-/* Test aid (host only, no GPU): the filter tree the f64 kernels' box steps walk — the f32 companion of every node of the tree above
+/* Test aid (host only, no GPU): the filter tree the kernels' box steps walk — the f32 companion of every node of the tree above
  * (same ids): boxes6_out[6 i ..] = {min.x, max.x, min.y, max.y, min.z, max.z} rounded OUTWARD to f32, links2_out[2 i ..] = {skip, info}
  * (info: the first child, or for a leaf its own id | 0x40000000; near-duplicate inner nodes have been taken out of these links),
  * f64_boxes_out[6 i ..] = the exact box {min[3], max[3]}; *filter_m_out >= every |coordinate| of the f32 boxes (0: filter off).

@@ -424,7 +424,7 @@ template <typename T> int ensure_uploaded(Scene& s, DeviceScene<T>& d) {
     if (upload_vec<DMSphere<T>>(f.mspheres, d.mspheres)) return -1;
     if (upload_vec<DTri<T>>(f.tris, d.tris)) return -1;
     if (upload_vec<DBvhNode<T>>(f.bvh, d.bvh)) return -1;
-    if (sizeof(T) == 8u) { std::vector<DFNode> fn(f.bvh_f); fn.push_back(DFNode{}); if (upload_raw(fn, d.bvh_f)) return -1; }      // (one padding record, as upload_vec)
+    { std::vector<DFNode> fn(f.bvh_f); fn.push_back(DFNode{}); if (upload_raw(fn, d.bvh_f)) return -1; }      // (one padding record, as upload_vec)
     if (upload_vec<DMaterial<T>>(f.materials, d.materials)) return -1;
     if (upload_vec<DTexture<T>>(f.textures, d.textures)) return -1;
     if (upload_vec<DMedium<T>>(f.media, d.media)) return -1;
@@ -550,7 +550,7 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choi
 
 // BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
 // queues and stacks; 0 for the list-scene kernels.
-template <typename T> size_t lds_node_bytes(uint32_t effective) { return filtered_walk(sizeof(T) == 8u, effective) ? sizeof(DFNode) : sizeof(DBvhNode<T>); }
+template <typename T> size_t lds_node_bytes(uint32_t effective) { return filtered_walk(effective) ? sizeof(DFNode) : sizeof(DBvhNode<T>); }
 template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat& f, const hipDeviceProp_t& prop, uint32_t stack_depth, uint32_t effective) {
     if (!g.one_per_cu || f.bvh.empty()) return 0u;
     size_t lds_total = (size_t)prop.maxSharedMemoryPerMultiProcessor;

@@ -541,7 +541,9 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
 struct BoxFilter { float ix, iy, iz, ax, bx, ay, by, az, bz, tmin, c; bool ok; };
 DEV float up32(double x) { x = x < -3.0e38 ? -3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f); }      // >= x
 DEV float down32(double x) { x = x > 3.0e38 ? 3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f); }   // <= x
-DEV BoxFilter make_filter(float M, V3<double> o, V3<double> inv, double t_min, double closest) {
+DEV float up32(float x) { return x; }
+DEV float down32(float x) { return x; }
+template <typename T> DEV BoxFilter make_filter(float M, V3<T> o, V3<T> inv, T t_min, T closest) {
     BoxFilter F;
     F.ix = (float)inv.x; F.iy = (float)inv.y; F.iz = (float)inv.z;
     const float jx = __builtin_fabsf(F.ix), jy = __builtin_fabsf(F.iy), jz = __builtin_fabsf(F.iz);
@@ -600,15 +602,15 @@ template <typename T> DEV uint32_t exact_step(const KParams<T>& P, uint32_t st, 
     return (nd.a & BVH_LEAF) ? (id | FNODE_LEAF) : state_of(P, nd.c);
 }
 // which instantiations walk this way (the host sizes the LDS node cache by the same rule: rt_launch.h filtered_walk)
-template <typename T, uint32_t FEATS> struct Filt { static constexpr bool on = sizeof(T) == 8u && (FEATS & F_BVH) != 0u && (FEATS & F_NEAR_FIRST) == 0u; };
+template <typename T, uint32_t FEATS> struct Filt { static constexpr bool on = (FEATS & F_BVH) != 0u && (FEATS & F_NEAR_FIRST) == 0u; };
 
 // Box steps and leaf steps are chosen by vote as in bvh_hit_ww.  SPEC (worlds that are one BVH: every lane walks): a lane does not wait
 // with one pending leaf, it walks on with its closest hit as it is and waits with two — every leaf is tested against its own box with
 // the closest hit of THAT moment in the leaf step anyway, so walking ahead with a stale (larger) bound only visits more.
-template <uint32_t FEATS, bool SPEC>
-DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out) {
-    const V3<double> inv = mk<double>(1.0 / ray.d.x, 1.0 / ray.d.y, 1.0 / ray.d.z);
-    double closest = t_max;
+template <typename T, uint32_t FEATS, bool SPEC>
+DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+    const V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
+    T closest = t_max;
     bool any = false;
     BoxFilter F = make_filter(P.filter_m, ray.o, inv, t_min, closest);
     const bool tame = P.bvh_tame != 0u && __ballot(!(ray_is_tame(ray.o, inv) && F.ok)) == 0ull;   // wave-uniform: every lane of this search
@@ -637,10 +639,10 @@ DEV bool bvh_hit_filt(const KParams<double>& P, uint32_t root, const RayT<double
         else while (__ballot(st_walking(node)) != 0ull) { if (st_walking(node)) node = exact_step(P, node, ray.o, inv, t_min, closest); }   // to every lane's next leaf
         const uint32_t leaf = (SPEC && p1 != ST_DONE) ? p1 : (st_pending(node) ? node & ~FNODE_LEAF : ST_DONE);
         if (leaf != ST_DONE) {
-            const DBvhNode<double> lf = ld_node_at(P.bvh, leaf);
-            double t; uint32_t prim;
+            const DBvhNode<T> lf = ld_node_at(P.bvh, leaf);
+            T t; uint32_t prim;
             if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
-                range_hit<double, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
+                range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
             if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
             else node = fnode_skip(P, leaf);
         }
@@ -715,7 +717,7 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
 
 template <typename T, uint32_t FEATS>
 DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
-    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<FEATS, (FEATS & F_SPEC) != 0u>(P, root, ray, t_min, t_max, t_out, prim_out);
+    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<T, FEATS, (FEATS & F_SPEC) != 0u>(P, root, ray, t_min, t_max, t_out, prim_out);
     return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack);
 }
 

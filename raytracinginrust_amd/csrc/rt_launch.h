@@ -13,9 +13,9 @@ inline size_t pathtrace_lds_bytes(const LaunchShape& g, uint32_t stack_depth, ui
     const size_t waves = g.threads / 64u;
     return (size_t)n_cached * node_bytes + waves * ((size_t)g.queue_entries * 80u + (size_t)stack_depth * 64u * sizeof(uint32_t));
 }
-// The f64 kernels walk a BVH in the reference's order through the f32 filter nodes (rt_ir.h DFNode, rt_kernel.hip bvh_hit_filt): those
-// are then what the LDS node cache holds.  The near-first order (opt-in) and the f32 kernels keep the plain nodes.
-inline bool filtered_walk(bool f64_kernels, uint32_t effective_flags) { return f64_kernels && !(effective_flags & 8u /* RT_NEAR_FIRST_BVH */); }
+// The kernels walk a BVH in the reference's order through the f32 filter nodes (rt_ir.h DFNode, rt_kernel.hip bvh_hit_filt): those are
+// then what the LDS node cache holds.  The near-first order (opt-in) keeps the plain nodes.
+inline bool filtered_walk(uint32_t effective_flags) { return !(effective_flags & 8u /* RT_NEAR_FIRST_BVH */); }
 // Counter block the kernel reports into: RT_STATS_ROWS copies (row = block index mod rows) of RT_STATS_SLOTS 64-bit counters
 static const uint32_t RT_STATS_SLOTS = 16u, RT_STATS_ROWS = 32u;
 static const size_t RT_STATS_BYTES = (size_t)RT_STATS_SLOTS * RT_STATS_ROWS * sizeof(unsigned long long);
