@@ -342,8 +342,9 @@ DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy,
     const float s1 = max3_nn(nrx, nry, nrz), s2 = med3_nn(nrx, nry, nrz), e1 = min3_nn(frx, fry, frz), e2 = med3_nn(frx, fry, frz);
     const float RHO = 0x1p-18f;
     const float A = (0x1p-40f * rect_m) * amax3(rx, ry, rz);
-    const float mu = __builtin_fmaf(RHO, __builtin_fmaxf(amax3(s1, e1, s2), __builtin_fabsf(e2)), A);
-    const bool order_clear = rect_m > 0.0f && s1 - s2 > mu && e2 - e1 > mu;
+    const float tm = __builtin_fmaxf(amax3(s1, e1, s2), __builtin_fabsf(e2));
+    const float mu = __builtin_fmaf(RHO, tm, A);
+    const bool order_clear = rect_m > 0.0f && tm < 1.0e36f && s1 - s2 > mu && e2 - e1 > mu;      // (1e36: far inside the +-1e37 that [t_min, t_max] is clamped to below)
     const bool through = e1 - s1 > mu, past = s1 - e1 > mu;              // enters before it leaves: the box is hit / leaves first: it is missed
     // a plane distance against [t_min, t_max], by more than the approximations can be off
     const float lo = __builtin_fmaxf((float)t_min, -1.0e37f), hi = __builtin_fminf((float)t_max, 1.0e37f);

@@ -931,6 +931,8 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe):
     d *= 10.0 ** rnd.uniform(-2, 2, (n, 1))
     axis_par = rnd.integers(0, 40, n) == 0
     d[axis_par, rnd.integers(0, 3, axis_par.sum())] = 0.0
+    tiny = rnd.integers(0, 50, n) == 1                                           # nearly axis-parallel: plane distances of 1e30 ... 1e45
+    d[tiny, rnd.integers(0, 3, tiny.sum())] = rnd.choice([-1.0, 1.0], tiny.sum()) * 10.0 ** rnd.uniform(-44, -28, tiny.sum())
     t_hit = np.linalg.norm(tgt - o, axis=1) / np.maximum(np.linalg.norm(d, axis=1), 1e-300)
     tmax = np.where(rnd.integers(0, 2, n) == 0, np.inf, t_hit * (1.0 + rnd.choice([-4, -1, 0, 1, 4, 1000, 1e6], n) * 2.0 ** -52))
     tmin = np.where(rnd.integers(0, 4, n) == 0, t_hit * (1.0 + rnd.choice([-4, -1, 0, 1, 4], n) * 2.0 ** -52), 1e-5)
@@ -950,6 +952,7 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe):
     hit_ref = ~np.isnan(t_ref)
     assert 0.15 * n < hit_ref.sum() < 0.9 * n
     assert not clear[axis_par].any()
+    assert clear[tiny].mean() < 0.5                                             # plane distances beyond 1e36 are never clear (the clamp of [t_min, t_max])
     bad = clear & ((face_fast != face_ref) | (t_fast.view(np.uint64) != t_ref.view(np.uint64)) & ~(np.isnan(t_fast) & np.isnan(t_ref)))
     assert not bad.any(), f"{int(bad.sum())} clear cases differ from the six rect tests, e.g. case {int(np.flatnonzero(bad)[0])}: " \
                           f"ref (t {t_ref[np.flatnonzero(bad)[0]]!r}, face {face_ref[np.flatnonzero(bad)[0]]}) fast (t {t_fast[np.flatnonzero(bad)[0]]!r}, face {face_fast[np.flatnonzero(bad)[0]]})"
@@ -959,7 +962,7 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe):
     bad2 = clear2 & (((out[:, 3].astype(int) & 7) - 1 != out[:, 1].astype(int)) | (out[:, 2].view(np.uint64) != out[:, 0].view(np.uint64)) & ~(np.isnan(out[:, 2]) & np.isnan(out[:, 0])))
     assert not bad2.any()
     # plain rays are (nearly) always clear: the fast path is what runs
-    plain = (kind == 4) & ~axis_par & ~thin & (np.isinf(tmax)) & (tmin == 1e-5)         # a random direction from a random origin
+    plain = (kind == 4) & ~axis_par & ~tiny & ~thin & (np.isinf(tmax)) & (tmin == 1e-5)   # a random direction from a random origin
     assert clear[plain].mean() > 0.99, clear[plain].mean()
 
 
