@@ -105,10 +105,11 @@ def cpu_baseline(w, sample_spp, earth=None):
             "note": "CPU restatement of the reference (oracle/), never the Rust binary; event counters compiled out"}
 
 
-def pmc_profile(workload_key):
-    """Per-dispatch counter means from the committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE /
-    WRITE_SIZE / SQ passes, tools/profile_pmc.sh), newest snapshot of this workload — used ONLY when it was taken on this
-    build of the kernels (the summary's kernel_source_id equals the hash of the kernel sources in this tree).  Returns
+def pmc_profile(workload_key, kernel=None):
+    """Per-dispatch counters of the TIMED frames from the committed rocprofv3 --pmc passes of this same command (separate FETCH_SIZE /
+    WRITE_SIZE / SQ passes, tools/profile_pmc.sh + tools/pmc_summary.py), newest snapshot of this workload — used ONLY when it was
+    taken on this build of the kernels (the summary's kernel_source_id equals the hash of the kernel sources in this tree) AND of the
+    instantiation this run launched (`kernel`, from rt_last_loop_info: a mesh scene may run either loop shape).  Returns
     (values, file name) or (None, reason)."""
     import csv
     import glob
@@ -120,11 +121,19 @@ def pmc_profile(workload_key):
     ident = [r["mean_per_dispatch"] for r in rows if r["counter"] == "kernel_source_id"]
     if not ident or ident[0] != buildinfo.kernel_source_id():
         return None, f"{os.path.basename(files[-1])} was taken on another build of the kernels (not used)"
-    vals = {r["counter"]: float(r["mean_per_dispatch"]) for r in rows if r["counter"] != "kernel_source_id"}
+    named = [r["mean_per_dispatch"] for r in rows if r["counter"] == "kernel"]
+    if kernel is not None and (not named or kernel not in named[0]):
+        return None, f"{os.path.basename(files[-1])} profiles {named[0] if named else 'an unnamed kernel'}, this run launched {kernel} (not used)"
+    vals = {}
+    for r in rows:
+        try:
+            vals[r["counter"]] = float(r["mean_per_dispatch"])
+        except ValueError:
+            pass                      # the identity rows (kernel, dispatch ids, kernel_source_id)
     return vals, os.path.basename(files[-1])
 
 
-def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
+def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc, instantiation=None):
     """The bench line's `roofline` object for one workload: f64 VALU issue (the real bound), BASELINE's algorithmic-bytes model
     beside it, both from THIS run's kernel time; PMC-derived fields only from a committed profile of this very build."""
     from raytracinginrust_amd import workloads
@@ -136,6 +145,10 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
     model = bps * local_samples / (k_ms * 1e-3) / 1e9
     roof = {"bound": "f64_valu", "achieved": achieved, "peak": peak, "unit": "Tops/s (f64 VALU issue-equivalents: lane-operations weighted by issue cost)",
             "frac": achieved / peak,
+            "frac_is": "REFERENCE-EQUIVALENT throughput against the issue peak: the reference's algorithmic f64 operations per sample x samples / s.  "
+                       "Not the share of issue slots the kernel fills — it executes fewer operations than the reference's arithmetic has (see "
+                       "achieved_counts); that share is `executed_valu_frac` (from the PMC counters of the timed frames, null without a profile of this build)",
+            "executed_valu_frac": None,
             "peak_measured_issue": workloads.F64_VALU_MEASURED_ISSUE_OPS / 1e12, "frac_of_measured_issue": achieved / (workloads.F64_VALU_MEASURED_ISSUE_OPS / 1e12),
             "traffic": None, "traffic_unit": "bytes per launch (PMC FETCH_SIZE + WRITE_SIZE, KB counters x 1024; raw values)",
             "traffic_source": None, "hbm_measured_GBps": None, "hbm_measured_frac": None,
@@ -164,7 +177,7 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
                                   "never come from HBM"}}
     valu = None
     if with_pmc:
-        vals, src = pmc_profile(w.key)
+        vals, src = pmc_profile(w.key, instantiation)
         if vals is None:
             roof["traffic_source"] = src
         else:
@@ -184,14 +197,21 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc):
                 valu = {"valu_busy_frac": busy, "valu_lane_utilisation": lanes, "frac": busy * lanes,
                         "frac_meaning": "useful VALU lane-slots (every VALU instruction, not only f64 arithmetic) / lane-slots the SIMDs could have issued over the launch",
                         "source": f"profiles/{src}: committed rocprofv3 --pmc passes of this command on this build (not measured in this run)"}
+                roof["executed_valu_frac"] = valu["frac"]
+                if "SQ_INSTS_VALU" in vals:
+                    valu["valu_wave_instructions_per_sample"] = vals["SQ_INSTS_VALU"] / local_samples
     return roof, valu
 
 
-def kernel_name_of(w, f32):
-    t = "float" if f32 else "double"
-    feats = {"cornell": "0 (lean: rects + instances + Lambertian/Metal/DiffuseLight)", "random": "the sphere-BVH instantiation",
-             "final": "the all-features-but-PBR instantiation", "teapot": "BVH|TRIS|PERSIST (mesh, persistent traversal)"}[w.scene]
-    return f"rt::pathtrace_kernel<{t}, FEATS>, FEATS = {feats}"
+FEAT_BITS = ((1, "BVH"), (2, "SPHERES"), (4, "TRIS"), (8, "MEDIUM"), (16, "TEXTURES"), (32, "DIELECTRIC"), (64, "PBR"), (128, "NEAR_FIRST"),
+             (256, "PERSIST (persistent traversal)"), (2048, "SPEC (walk-ahead filtered walk)"))
+
+
+def kernel_name_of(loop):
+    """The instantiation that RAN, as the library reports it (rt_last_loop_info) — the name a rocprofv3 trace shows."""
+    feats = loop["feats"]
+    bits = " | ".join(n for b, n in FEAT_BITS if feats & b) or "lean: rects + instances + Lambertian / Metal / DiffuseLight"
+    return f"{loop['kernel']} ({bits}; loop shape {loop['shape']}, chosen by: {loop['chosen_by']})"
 
 
 def resolve_mode(mode, gpus, env_world):
@@ -230,6 +250,11 @@ def main():
                     help="after the timed region, render two rows of the frame again on rank 0's device alone and compare them with the step's frame "
                          "(`multi_check`).  auto = at N > 1 (where a wrong un-permute, an idle rank or a stale buffer could hide); at N = 1 it would only add "
                          "two small launches of the same kernel to a profiler's per-kernel averages")
+    ap.add_argument("--loop", default="auto", choices=("auto", "persistent", "lockstep"),
+                    help="mesh scenes (C4): which loop shape runs — same samples either way.  auto = measured for the view before the warm-up "
+                         "(rt_scene_calibrate: four small launches outside every timed region; at N > 1 rank 0's result is handed to every rank); "
+                         "the other two set it (rt_scene_set_loop_shape) and skip the measurement — what a profiled run uses so that no "
+                         "calibration launch lands in its per-kernel averages.  No effect on the other scenes")
     ap.add_argument("--cpu-spp", type=int, default=-1, help="spp of the bounded CPU-baseline sample (0 = skip, -1 = sized for ~8 s of wall time)")
     args = ap.parse_args()
 
@@ -304,6 +329,21 @@ def main():
             R.set_bvh_builder(b, R.RT_BVH_SAH)
         return b, cam, bg
 
+    def settle_loop_shape(b, cam, bg, w):
+        """Mesh scenes: fix the loop shape before anything is timed.  The asynchronous entry points the steps use never measure it
+        themselves (they would have to wait), so: --loop auto measures it here for this very view — on rank 0's device, and every
+        rank then runs what rank 0 found (ranks measuring alone could disagree and the line could not say what ran)."""
+        if args.loop != "auto":
+            R.set_loop_shape(b, 1 if args.loop == "persistent" else 0)
+            return
+        if rank == 0:
+            R.calibrate(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags)
+        if world > 1:
+            ch = torch.tensor([R.stored_loop_shape(b) if rank == 0 else -1], dtype=torch.int64, device=cdev)
+            dist.broadcast(ch, src=0)
+            if rank != 0 and int(ch.item()) >= 0:
+                R.set_loop_shape(b, int(ch.item()))
+
     def check_rows(b, cam, bg, w, frame_rows):
         """Self-validation of a frame, outside every timed region: rows H/2 and H/2 + 1 of the SAME frame rendered again on this device
         alone — tile = one image row, world = H, rank = the row: one launch per row, no sharding, no gather, no un-permute — against
@@ -333,6 +373,7 @@ def main():
         b, cam, bg = build_scene(w)
         # one-time initialisation (scene flatten + upload, code-object load, event creation) is not part of a step
         R.prepare(b, flags)
+        settle_loop_shape(b, cam, bg, w)
         if warmup:
             tw = D.TileRenderer(b, cam, bg, w.W, w.H, warm_spp or w.spp, w.max_depth, flags=flags, tile_px=args.tile_px, rank=rank, world=world,
                                 pipeline=pipeline)
@@ -353,7 +394,7 @@ def main():
         k_total_ms, k_launches = R.kernel_time_total(b)
         assert k_launches == steps
         res = {"w": w, "elapsed": elapsed, "steps": steps, "k_ms": k_total_ms / k_launches, "stats": R.last_stats(b), "n_flush": R.last_flush_count(b),
-               "pipeline": tr.pipeline, "multi_ms": None, "stats_scope": "rank 0's share" if world > 1 else "frame"}
+               "pipeline": tr.pipeline, "multi_ms": None, "stats_scope": "rank 0's share" if world > 1 else "frame", "loop": R.last_loop_info(b)}
         n_px = w.W * w.H                     # real (unpadded) pixels this rank's launch owns
         local_px = sum(max(0, min(n_px, (t + 1) * args.tile_px) - t * args.tile_px)
                        for t in D.local_tile_ids(w.W, w.H, args.tile_px, rank, world) if t * args.tile_px < n_px)
@@ -379,6 +420,8 @@ def main():
         the un-permute on the first device — with the frame left in that device's memory (as the N = 1 bench leaves it); the calls do
         not wait for each other's frames beyond what the library's one-frame-in-flight rule asks for."""
         b, cam, bg = build_scene(w)
+        R.prepare(b, flags)
+        settle_loop_shape(b, cam, bg, w)        # on this process's current device; the stored shape serves every device's launch of this view
         for _ in range(max(1, warmup)):         # (the first call also creates the communicators and uploads the scene everywhere)
             R.render_multi_device(b, cam, bg, w.W, w.H, (warm_spp or w.spp) if warmup else 1, w.max_depth, device_mask, flags=flags, tile_px=args.tile_px)
         R.multi_sync(b)
@@ -402,6 +445,7 @@ def main():
                "pipeline": 1, "multi_ms": R.last_multi_ms(b), "mean_radiance": float(np.nan_to_num(frame).mean()) / w.spp,
                "local_samples": w.samples / n_gpus,            # per launch: k_ms is the mean over the frame's N launches, so is this
                "stats_scope": "frame",                         # rt_last_stats sums the counters of the frame's N launches
+               "loop": R.last_loop_info(b),
                "ranks": {"ranks_seen": rk["collective_ranks"] if rk["collective_ranks"] else rk["n_ranks"],
                          "ranks_seen_source": "ncclCommCount of the gather's communicator" if rk["collective_ranks"] else
                                               "launches of the frame (no collective ran: virtual ranks on one device)",
@@ -429,7 +473,8 @@ def main():
 
     if rank == 0:
         with_pmc = n_gpus == 1 and not args.f32 and not args.near_first and not args.sah
-        roof, valu = roofline_of(w, main_res["local_samples"], main_res["k_ms"], main_res["n_flush"], kernel_name_of(w, args.f32), with_pmc)
+        roof, valu = roofline_of(w, main_res["local_samples"], main_res["k_ms"], main_res["n_flush"], kernel_name_of(main_res["loop"]), with_pmc,
+                                 main_res["loop"]["kernel"])
         cpu = None
         if n_gpus == 1 and args.cpu_spp != 0 and not args.f32:
             cpu = cpu_baseline(w, args.cpu_spp, earth)
@@ -437,7 +482,7 @@ def main():
         others = {}
         for r in extra:
             we = r["w"]
-            ro, va = roofline_of(we, r["local_samples"], r["k_ms"], r["n_flush"], kernel_name_of(we, args.f32), with_pmc)
+            ro, va = roofline_of(we, r["local_samples"], r["k_ms"], r["n_flush"], kernel_name_of(r["loop"]), with_pmc, r["loop"]["kernel"])
             others[we.key] = {"workload": we.describe(), "value": we.samples * r["steps"] / r["elapsed"] / 1e6, "unit": "Msamples/s", "steps": r["steps"],
                               "warmup": f"1 frame at {max(1, we.spp // 32)} spp (same kernel and scene)", "ms_per_step": r["elapsed"] / r["steps"] * 1e3,
                               "kernel_ms": r["k_ms"], "frac": ro["frac"], "frac_unweighted": ro["frac_unweighted"], "frac_of_measured_issue": ro["frac_of_measured_issue"],
@@ -446,7 +491,7 @@ def main():
                               "hbm_measured_GBps": ro["hbm_measured_GBps"], "hbm_measured_frac": ro["hbm_measured_frac"],
                               "bytes_per_sample": ro["model_hbm"]["bytes_per_sample"],
                               "model_hbm_GBps": ro["model_hbm"]["achieved_GBps"], "traffic": ro["traffic"], "traffic_source": ro["traffic_source"],
-                              "valu_pmc": va, "kernel": ro["kernel"], "multi_ms": r["multi_ms"],
+                              "valu_pmc": va, "executed_valu_frac": ro["executed_valu_frac"], "kernel": ro["kernel"], "loop": r["loop"], "multi_ms": r["multi_ms"],
                               "lane_utilisation": r["stats"]["live_lane_iterations"] / max(1, 64 * r["stats"]["wave_iterations"]),
                               "nonfinite_samples": r["stats"]["nonfinite_samples"], "nonfinite_samples_scope": r["stats_scope"],
                               "mean_radiance": r["mean_radiance"], "multi_check": r.get("multi_check"), "ranks": r.get("ranks")}
@@ -463,7 +508,7 @@ def main():
             "config": {"workload": f"{w.key}: {w.describe()}", "tile_px": args.tile_px, "seed": "0x5EED",
                        "parallelism": par, "mode": "inproc" if inproc else ("procs" if n_gpus > 1 else "single"),
                        "frames_in_flight": main_res["pipeline"]},
-            "roofline": roof, "valu_pmc": valu, "cpu_baseline": cpu, "workloads": others,
+            "roofline": roof, "valu_pmc": valu, "loop": main_res["loop"], "cpu_baseline": cpu, "workloads": others,
             "lane_utilisation": st["live_lane_iterations"] / max(1, 64 * st["wave_iterations"]),
             "nonfinite_samples": st["nonfinite_samples"], "nonfinite_samples_scope": main_res["stats_scope"], "mean_radiance": main_res["mean_radiance"],
         }

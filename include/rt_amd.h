@@ -47,8 +47,8 @@ enum {
                               on the order hits are found.                                                                   */
     RT_PERSISTENT_BVH = 16, /* scheduling only, same samples: lanes keep their place inside a BVH while the rest of the wavefront
                               shades / regenerates (mesh kernels).  Chosen automatically for triangle-mesh BVHs that stand
-                              beside other top-level objects: by tree size, or — frames of >= 1e8 samples — by timing both loops
-                              on a small copy of the view at the scene's first render; this flag forces it on ...            */
+                              beside other top-level objects: by tree size, or by a calibration of the view (rt_scene_calibrate;
+                              rt_render / rt_render_multi run one at a scene's first frame of >= 1e8 samples); this flag forces it on ... */
     RT_LOCKSTEP_BVH = 32,  /* ... and this one forces the lock-step loop                                                      */
     RT_MULTI_COLLECTIVE = 64, /* rt_render_multi only: run the RCCL gather even when one device is selected (a one-GPU box then
                               exercises the same collective calls as an 8-GPU node)                                          */
@@ -164,6 +164,9 @@ int rt_render_device(rt_scene*, const rt_camera*, const double background[3], ui
                      uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags,
                      uint32_t tile_px, uint32_t rank, uint32_t world_size,
                      void* d_out, size_t d_out_bytes, void* hip_stream);
+/* (rt_render_device and rt_render_multi_device never wait: everything that has to — the first use of a scene on a device, see
+ * rt_scene_prepare, and the loop-shape calibration of a mesh scene, see rt_scene_calibrate — is done inside them only as far as it can
+ * be done without a wait; call those two first where it matters.) */
 /* The whole frame on several GPUs of this node from ONE call: what a host that owns the node's GPUs itself (the reference's `main`,
  * src/main.rs:767-835) calls instead of rt_render.  device_mask: bit d selects HIP device d (0 = every visible device).  The scene
  * is replicated on each selected device; tiles of tile_px output-order pixels (0 = the default, 67) are dealt round-robin, each
@@ -212,6 +215,24 @@ int rt_scene_set_bvh_builder(rt_scene*, int mode);
 /* Optional: do now what the first render of this scene would do once inside its call (flatten, upload for the precision in
  * `flags`, load the kernel's code object).  Launches nothing. */
 int rt_scene_prepare(rt_scene*, uint32_t flags);
+/* Mesh scenes (triangle-mesh BVHs beside other top-level objects) run a persistent-traversal or a lock-step loop — bit-identical samples;
+ * which is faster depends on what the rays of a VIEW do inside the trees, not on the trees' size.  rt_scene_calibrate measures it:
+ * the same view at <= 1024 x 1024 x 16 samples, twice in each shape (four launches, ~30 ms), SYNCHRONOUSLY on the calling thread's
+ * current device, and keeps the faster shape for that view (camera, W, H, precision; another view falls back to the size rule until it
+ * is calibrated itself; a change to the scene forgets everything).  A no-op for every other kind of scene and for a view already
+ * measured.  rt_render, rt_render_samples and rt_render_multi do this themselves at a scene's first frame of >= 1e8 samples;
+ * rt_render_device and rt_render_multi_device — asynchronous — never do.
+ * rt_scene_set_loop_shape: 1 persistent traversal, 0 lock-step, for every view until the scene changes, -1 forgets (how the ranks of a
+ * one-process-per-GPU job all run the shape rank 0 measured).
+ * rt_last_loop_info: what the most recent launch ran — out4[0] loop shape (0: a list scene's kernel, 1: lock-step BVH, 2: persistent
+ * traversal), [1] the FEATS template argument of the instantiation (its name in a profile: rt::pathtrace_kernel<double, FEATSu>),
+ * [2] how the shape was chosen (0 the scene leaves no choice, 1 size rule, 2 calibration, 3 the caller's flag, 4 rt_scene_set_loop_shape),
+ * [3] precision (0 f64, 1 f32); calibration_ms2 (may be NULL): the stored calibration's kernel times {lock-step, persistent}, 0 if none. */
+int rt_scene_calibrate(rt_scene*, const rt_camera*, const double background[3], uint32_t W, uint32_t H,
+                       uint32_t samples_per_pixel, uint32_t max_depth, uint64_t seed, uint32_t flags);
+int rt_scene_set_loop_shape(rt_scene*, int shape);
+int rt_scene_loop_shape(rt_scene*);      /* the stored shape: 1 / 0, -1 none (a calibration's result applies to the view it measured) */
+int rt_last_loop_info(rt_scene*, int32_t out4[4], float calibration_ms2[2]);
 /* Milliseconds of the most recent path-tracing kernel launched by this library on this thread's scene,
  * from HIP events recorded on the launch stream (blocks until that kernel finishes). */
 int rt_last_kernel_ms(rt_scene*, float* ms_out);

@@ -1391,6 +1391,46 @@ void orc_reflect(const double* v, const double* n, double* out) { Vec3 r = V(v).
 void orc_refract(const double* v, const double* n, double eta, double* out) { Vec3 r = V(v).refract(V(n), eta); for (int i = 0; i < 3; i++) out[i] = r[i]; }
 double orc_reflectance(double cosine, double ir) { return Dielectric::reflectance(cosine, ir); }
 void orc_onb(const double* n, double* out9) { ONB o = ONB::build_from_w(V(n)); for (int a = 0; a < 3; a++) for (int i = 0; i < 3; i++) out9[a * 3 + i] = o.axis[a][i]; }
+// Cube::hit (cube.rs:35-37: HittableList::hit, hit.rs:59-71, over the six AARects of cube.rs:17-24) for n (cube, ray, [t_min, t_max])
+// cases: boxes n x (min[3], max[3]), rays n x (origin[3], direction[3]), tlim n x (t_min, t_max); out[2 i] = the hit's t (NaN: none),
+// out[2 i + 1] = the accepted face's index in cube.rs:17-24 order (-1: none) — the face is read off the returned record (which of
+// the six planes the hit position's plane coordinate and normal belong to is found by walking the list the way hit.rs does).
+void orc_cube_hit_batch(uint32_t n, const double* boxes, const double* rays, const double* tlim, double* out) {
+    Sampler tmp; tmp.rng = Rng::for_stream(0, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const Cube c(V(boxes + 6 * i), V(boxes + 6 * i + 3), nullptr);
+        const Ray r(V(rays + 6 * i), V(rays + 6 * i + 3), 0.0);
+        HitRecord rec;
+        const bool any = c.hit(r, tlim[2 * i], tlim[2 * i + 1], tmp, rec);
+        int face = -1;
+        if (any) {      // the same scan as HittableList::hit, keeping the index of the item whose record was kept
+            double closest = tlim[2 * i + 1]; HitRecord t2; int k = 0;
+            for (const Hittable* side : c.sides.list) { if (side->hit(r, tlim[2 * i], closest, tmp, t2)) { closest = t2.t; face = k; } k++; }
+            if (!(closest == rec.t)) face = -2;      // (cannot happen: the two scans are the same code)
+        }
+        out[2 * i] = any ? rec.t : double(std::nan(""));
+        out[2 * i + 1] = (double)face;
+    }
+}
+// what built this library (bench.py's cpu_baseline reports it instead of a sentence)
+const char* orc_build_info() {
+    return "g++ " __VERSION__
+#ifdef __OPTIMIZE__
+           ", optimised"
+#else
+           ", NOT optimised"
+#endif
+#ifdef __FAST_MATH__
+           ", -ffast-math (!)"
+#endif
+#ifdef ORC_NO_COUNTERS
+           ", event counters compiled out"
+#endif
+#ifdef ORC_COUNT_OPS
+           ", op-counting build"
+#endif
+           ;
+}
 int orc_aabb_hit(const double* mn, const double* mx, const double* o, const double* d, double t_in, double t_out) { return AABB(V(mn), V(mx)).hit(Ray(V(o), V(d), 0.0), t_in, t_out) ? 1 : 0; }
 // generic hit on any hittable handle: out = position(3) normal(3) t u v front_face(0/1)
 int orc_hit(void* s, int h, const double* o, const double* d, double time, double t_min, double t_max, void* rng, double* out10) {

@@ -34,7 +34,7 @@ FRAMEBUFFER_BYTES_PER_PIXEL = 12
 
 _backend = None
 NOCOUNT_LIB_PATH = os.path.join(_HERE, "_build", "liboracle_nocount.so")
-BUILD_INFO = {"compiler": "g++ (see `g++ --version` of the build host; 11.4 in the round-2 image)",
+BUILD_INFO = {"compiler": None,      # filled in by load_nocount() from the library's own __VERSION__ (orc_build_info)
               "flags": "-O3 -std=c++17 -ffp-contract=off -fno-fast-math -pthread, baseline x86-64 (no -march=native: built on one host, "
                        "run on another); event counters compiled out (-DORC_NO_COUNTERS)"}
 _nocount = None
@@ -47,6 +47,7 @@ def load_nocount() -> Backend:
         if not os.path.exists(NOCOUNT_LIB_PATH):
             build()
         _nocount = _declare(C.CDLL(NOCOUNT_LIB_PATH))
+        BUILD_INFO["compiler"] = _nocount.lib.orc_build_info().decode()
     return _nocount
 
 
@@ -97,6 +98,9 @@ def _declare(lib) -> Backend:
     lib.orc_render.argtypes = [C.c_void_p, cam_p, c_double_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64,
                                C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.orc_hardware_threads.restype = C.c_int
+    lib.orc_build_info.restype = C.c_char_p
+    lib.orc_cube_hit_batch.restype = None
+    lib.orc_cube_hit_batch.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     d3 = c_double_p
     lib.orc_sphere_uv.argtypes = [d3, d3]
     lib.orc_reflect.argtypes = [d3, d3, d3]

@@ -87,6 +87,15 @@ def load_path(path: str) -> Backend:
     lib.rt_scene_set_bvh_builder.argtypes = [C.c_void_p, C.c_int]
     lib.rt_scene_prepare.restype = C.c_int
     lib.rt_scene_prepare.argtypes = [C.c_void_p, C.c_uint32]
+    if hasattr(lib, "rt_scene_calibrate"):           # (round 6; tools/ab.py also loads builds of earlier rounds)
+        lib.rt_scene_calibrate.restype = C.c_int
+        lib.rt_scene_calibrate.argtypes = common
+        lib.rt_scene_set_loop_shape.restype = C.c_int
+        lib.rt_scene_set_loop_shape.argtypes = [C.c_void_p, C.c_int]
+        lib.rt_scene_loop_shape.restype = C.c_int
+        lib.rt_scene_loop_shape.argtypes = [C.c_void_p]
+        lib.rt_last_loop_info.restype = C.c_int
+        lib.rt_last_loop_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
     lib.rt_last_kernel_ms.restype = C.c_int
     lib.rt_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.rt_last_stats.restype = C.c_int

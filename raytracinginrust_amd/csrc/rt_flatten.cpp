@@ -439,7 +439,11 @@ void make_filter_nodes(HostFlat& f) {
     // profiles/r05_collapse_sweep.log) 0.5 — the break-even if a box were hit in proportion to its area — is far too eager (final scene
     // 2.5x slower: rays are culled by the closest hit, not by area), 0.7 - 0.8 is best on all three BVH scenes (+2 ... +4 %).
     double tau = 0.75;
-    if (const char* v = std::getenv("RT_COLLAPSE_TAU")) tau = std::atof(v);       // A/B runs only (>= 1: no contraction)
+    if (const char* v = std::getenv("RT_COLLAPSE_TAU")) {       // A/B runs only (>= 1: no contraction).  An empty or garbled value is ignored — read as 0 it
+        char* end = nullptr;                                    // would contract every inner node away and leave a near-linear scan of the leaves —
+        const double t = std::strtod(v, &end);                  // and anything below the surface-area break-even is clamped to it
+        if (end != v && *end == '\0' && std::isfinite(t)) tau = std::min(2.0, std::max(0.5, t));
+    }
     auto area = [&](const DBvhNode<double>& b) { const double dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2]; return dx * dy + dy * dz + dz * dx; };
     std::vector<uint32_t> parent(n, 0xFFFFFFFFu), redirect(n);
     for (size_t i = 0; i < n; i++) if (!(f.bvh[i].a & BVH_LEAF)) { parent[f.bvh[i].c] = (uint32_t)i; parent[f.bvh[i].b] = (uint32_t)i; }

@@ -63,6 +63,7 @@ void rt_scene_destroy(rt_scene* sc) {
     int cur = 0; (void)hipGetDevice(&cur);
     rt::multi_release(sc->s);
     if (sc->s.d_trace) { (void)hipSetDevice(sc->s.trace_device); (void)hipFree(sc->s.d_trace); sc->s.d_trace = nullptr; (void)hipSetDevice(cur); }
+    if (sc->s.d_calib) { (void)hipSetDevice(sc->s.calib_device); (void)hipDeviceSynchronize(); (void)hipFree(sc->s.d_calib); sc->s.d_calib = nullptr; (void)hipSetDevice(cur); }
     for (Scene::DeviceCtx* c : sc->s.ctxs) {
         (void)hipSetDevice(c->device);
         free_device_scene(c->dev64);
@@ -521,10 +522,12 @@ static bool loop_shape_is_open(const HostFlat& f, uint32_t flags, size_t* n_bvh_
     if (n_bvh_objects_out) *n_bvh_objects_out = n_bvh_objects;
     return n_bvh_objects != 0 && n_bvh_objects < f.objects.size();
 }
-static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choice = -1) {
+static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choice = -1, int* how_out = nullptr) {
     uint32_t out = flags;
     size_t n_bvh_objects = 0;
+    if (how_out) *how_out = (flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) ? 3 : 0;
     if (loop_shape_is_open(f, flags, &n_bvh_objects)) {
+        if (how_out) *how_out = loop_choice >= 0 ? 2 : 1;
         // Measured for this scene and view where a frame is big enough to be worth two small calibration launches (calibrate_loop_shape);
         // otherwise by tree size: *measured* (tools/mesh_size_probe.py: a lit room with one / two random triangle meshes, persistent ÷
         // lock-step kernel time; round 4 / round 5 with the filtered walk) one tree of 63 / 199 / 599 / 1999 / 5999 nodes 1.24 / 1.09 / 0.99 /
@@ -546,6 +549,21 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choi
         if (!can || (flags & RT_NO_SPECULATE_BVH)) out &= ~(uint32_t)RT_SPECULATE_BVH;
     }
     return out;
+}
+
+// The view a calibration is valid for: camera, frame size, precision (FNV-1a over their bytes).
+static unsigned long long loop_view_key(const rt_camera* cam, uint32_t W, uint32_t H, uint32_t flags) {
+    unsigned long long h = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    const uint32_t tail[3] = {W, H, flags & (uint32_t)RT_F32};
+    mix(cam, sizeof(rt_camera_args)); mix(tail, sizeof(tail));
+    return h ? h : 1ull;
+}
+// The stored loop shape as it applies to this view: a calibration only for the view it measured, a set shape for every view.
+static int loop_choice_for(const Scene& s, const rt_camera* cam, uint32_t W, uint32_t H, uint32_t flags) {
+    if (s.loop_choice < 0) return -1;
+    if (s.loop_how == 4) return s.loop_choice;
+    return (s.loop_how == 2 && s.loop_key == loop_view_key(cam, W, H, flags)) ? s.loop_choice : -1;
 }
 
 // BVH nodes (depth order: the top levels first) that fit into the LDS a one-workgroup-per-CU kernel leaves free beside its waves'
@@ -598,7 +616,9 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
         P.cam.cu[k] = (T)cam.cu[k]; P.cam.cv[k] = (T)cam.cv[k]; P.background[k] = (T)bg[k];
     }
     P.cam.lens_radius = (T)cam.lens_radius; P.cam.time0 = (T)cam.time0; P.cam.time1 = (T)cam.time1;
-    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; P.flags = effective_flags(f, flags, s.loop_choice);
+    P.W = W; P.H = H; P.spp = spp; P.max_depth = max_depth; P.seed = seed; int loop_how = 0;
+    P.flags = effective_flags(f, flags, loop_choice_for(s, camp, W, H, flags), &loop_how);
+    if (loop_how == 2 && s.loop_how == 4) loop_how = 4;
     P.stack_depth = stack_depth_of(f, P.flags);
     P.tile_px = tile_px; P.rank = rank; P.world = world;
     P.n_local_tiles = rt_local_tiles(W, H, tile_px, rank, world);
@@ -689,6 +709,9 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     s.last_device = c.device;
     s.launch_info[0] = (uint32_t)n_blocks; s.launch_info[1] = shape.threads; s.launch_info[2] = (uint32_t)shmem; s.launch_info[3] = P.n_cached;
     s.launch_info[4] = (uint32_t)f.bvh.size(); s.launch_info[5] = (uint32_t)bpc;
+    s.last_loop[1] = (int)pathtrace_feats(f.feats, P.flags);
+    s.last_loop[0] = !(f.feats & F_BVH) ? 0 : ((s.last_loop[1] & (int)F_PERSIST) ? 2 : 1);
+    s.last_loop[2] = (f.feats & F_BVH) ? loop_how : 0; s.last_loop[3] = sizeof(T) == 4 ? 1 : 0;
     return 0;
 }
 
@@ -702,54 +725,63 @@ int check_frame_args(rt_scene* sc, const rt_camera* cam, const double* bg, uint3
 
 // Mesh scenes: which loop shape is faster depends on what the rays of THIS view do inside the trees (a closed surface that fills a third
 // of the frame: the persistent loop by 10 %; a sparse cloud of triangles in a corner: the lock-step loop by 10 ... 80 %), not on anything
-// the flattener can see.  Both give the same samples bit for bit, so the first render of a frame that is worth it (>= 1e8 samples) first
-// renders the same view at <= 1024 x 1024 x 16 twice in each shape, on the caller's stream, and keeps the faster one for the scene
-// (Scene::loop_choice; forgotten when the scene changes).  Within 3 % of each other the size rule stands.  The calibration launches do
-// not count in rt_kernel_time_total and leave no trace in rt_last_* (the render that follows overwrites them).
+// the flattener can see.  Both give the same samples bit for bit, so a calibration renders the same view at <= 1024 x 1024 x 16 twice in
+// each shape and keeps the faster one FOR THAT VIEW (Scene::loop_key: camera, frame size, precision; forgotten when the scene changes).
+// Within 3 % of each other the size rule stands.  It is a SYNCHRONOUS piece of work (it waits for every launch of the scene, reads four
+// event pairs) and therefore runs only where the caller is synchronous anyway: rt_scene_calibrate, and the first render of a frame of
+// >= 1e8 samples through rt_render / rt_render_samples / rt_render_multi.  The asynchronous entry points (rt_render_device,
+// rt_render_multi_device) never calibrate: they use what is stored for their view, else the size rule.  The calibration launches do not
+// count in rt_kernel_time_total and leave no trace in rt_last_* (the render that follows overwrites them); their frame buffer is kept
+// with the scene (no allocation, no hipFree — which would synchronise the device — after the first time).
 static int calibrate_loop_shape(Scene& s, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
-                                uint64_t seed, uint32_t flags, hipStream_t stream) {
-    if (s.loop_choice >= 0 || !loop_shape_is_open(s.flat, flags) || (flags & RT_NEAR_FIRST_BVH) || (uint64_t)W * H * spp < 100000000ull) return 0;
-    if (std::getenv("RT_NO_LOOP_CALIBRATION")) return 0;                   // A/B runs and tests of the size rule
+                                uint64_t seed, uint32_t flags, hipStream_t stream, bool only_if_worth_it) {
+    if (!loop_shape_is_open(s.flat, flags) || (flags & RT_NEAR_FIRST_BVH)) return 0;
+    if (s.loop_how == 4 || loop_choice_for(s, cam, W, H, flags) >= 0) return 0;          // a shape was set, or this view has been measured
+    if (only_if_worth_it && ((uint64_t)W * H * spp < 100000000ull || std::getenv("RT_NO_LOOP_CALIBRATION"))) return 0;   // (the variable: A/B runs and tests of the size rule)
     // (the copies must be far above the ~0.5 ms a persistent launch spends filling and draining the chip, and long enough for the loops'
-    // steady state: *measured* on the teapot room, persistent ÷ lock-step 1.05 at 4 M samples, 0.94 at 20 M, 0.92 at 41 M, 0.85 at 4 G)
+    // steady state: *measured* on the teapot room, persistent / lock-step 1.05 at 4 M samples, 0.94 at 20 M, 0.92 at 41 M, 0.85 at 4 G)
     uint32_t k = 1; while ((uint64_t)(W / k) * (H / k) > 1048576ull) k++;
     const uint32_t Wc = std::max(2u, W / k), Hc = std::max(2u, H / k), sc_spp = std::min(spp, 16u);
-    void* d_tmp = nullptr;
     const size_t bytes = (size_t)Wc * Hc * 3 * sizeof(double);
-    HIP_OK(hipMalloc(&d_tmp, bytes));
-    if (settle_all_launches(s)) { (void)hipFree(d_tmp); return -1; }
+    int dev = 0; HIP_OK(hipGetDevice(&dev));
+    if (settle_all_launches(s)) return -1;
+    if (!s.d_calib || s.calib_device != dev || s.calib_bytes < bytes) {
+        if (s.d_calib) { DeviceGuard guard(s.calib_device); (void)hipDeviceSynchronize(); (void)hipFree(s.d_calib); s.d_calib = nullptr; }
+        HIP_OK(hipMalloc(&s.d_calib, bytes));
+        s.calib_device = dev; s.calib_bytes = bytes;
+    }
     const double keep_ms = s.kernel_ms_total; const unsigned long long keep_n = s.kernel_launches_timed;
     // (inside an rt_render_multi* frame the N launches share one frame number: the calibration launches get their own, and the frame a fresh one)
     const bool in_group = s.group_open; s.group_open = false;
     float best[2] = {1e30f, 1e30f};
-    int rc = 0, dev = 0; (void)hipGetDevice(&dev);
+    int rc = 0;
     for (int round = 0; round < 2 && rc == 0; round++)
         for (int shape = 0; shape < 2 && rc == 0; shape++) {
             const uint32_t fl = flags | (shape ? RT_PERSISTENT_BVH : RT_LOCKSTEP_BVH);
-            rc = (flags & RT_F32) ? render_impl<float>(s, cam, bg, Wc, Hc, sc_spp, max_depth, seed, fl, Wc * Hc, 0, 1, d_tmp, bytes, nullptr, stream)
-                                  : render_impl<double>(s, cam, bg, Wc, Hc, sc_spp, max_depth, seed, fl, Wc * Hc, 0, 1, d_tmp, bytes, nullptr, stream);
+            rc = (flags & RT_F32) ? render_impl<float>(s, cam, bg, Wc, Hc, sc_spp, max_depth, seed, fl, Wc * Hc, 0, 1, s.d_calib, bytes, nullptr, stream)
+                                  : render_impl<double>(s, cam, bg, Wc, Hc, sc_spp, max_depth, seed, fl, Wc * Hc, 0, 1, s.d_calib, bytes, nullptr, stream);
             float ms = 0.f;
             if (rc == 0 && device_kernel_ms(s, dev, &ms) == 0) best[shape] = std::min(best[shape], ms); else rc = -1;
         }
     if (settle_all_launches(s)) rc = -1;
     s.kernel_ms_total = keep_ms; s.kernel_launches_timed = keep_n;
     s.group_open = in_group; if (in_group) s.frame_group++;
-    (void)hipFree(d_tmp);
     if (rc != 0) return -1;
     if (best[1] < 0.97f * best[0]) s.loop_choice = 1;
     else if (best[0] < 0.97f * best[1]) s.loop_choice = 0;
     else s.loop_choice = (effective_flags(s.flat, flags, -1) & RT_PERSISTENT_BVH) ? 1 : 0;
+    s.loop_how = 2; s.loop_key = loop_view_key(cam, W, H, flags); s.loop_ms[0] = best[0]; s.loop_ms[1] = best[1];
     return 0;
 }
 
 int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
-               void* d_samples, hipStream_t stream) {
+               void* d_samples, hipStream_t stream, bool may_calibrate) {
     if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
     if (tile_px == 0 || world == 0 || rank >= world) return set_err("bad tile decomposition");
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
-    if (calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, stream)) return -1;
+    if (may_calibrate && calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, stream, true)) return -1;
     if (flags & RT_F32) return render_impl<float>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
     return render_impl<double>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
 }
@@ -760,7 +792,31 @@ extern "C" {
 
 int rt_render_device(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                      uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes, void* hip_stream) {
-    return render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, nullptr, (hipStream_t)hip_stream);
+    return render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, nullptr, (hipStream_t)hip_stream, false);
+}
+
+// Mesh scenes: measure which loop shape is faster for this view (see calibrate_loop_shape) — synchronous, on the calling thread's current
+// device; a no-op for every other scene, for a view already measured and after rt_scene_set_loop_shape.
+int rt_scene_calibrate(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                       uint64_t seed, uint32_t flags) {
+    if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
+    if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    return calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, nullptr, false);
+}
+int rt_scene_set_loop_shape(rt_scene* sc, int shape) {
+    if (!sc) return set_err("null argument");
+    if (shape < -1 || shape > 1) return set_err("rt_scene_set_loop_shape: -1 (forget), 0 (lock-step) or 1 (persistent traversal)");
+    sc->s.loop_choice = shape; sc->s.loop_how = shape < 0 ? 0 : 4;
+    if (shape < 0) sc->s.loop_ms[0] = sc->s.loop_ms[1] = 0.f;
+    return 0;
+}
+int rt_scene_loop_shape(rt_scene* sc) { return sc ? sc->s.loop_choice : -1; }
+int rt_last_loop_info(rt_scene* sc, int32_t out4[4], float calibration_ms2[2]) {
+    if (!sc || !out4) return set_err("null argument");
+    for (int k = 0; k < 4; k++) out4[k] = sc->s.last_loop[k];
+    if (calibration_ms2) { calibration_ms2[0] = sc->s.loop_ms[0]; calibration_ms2[1] = sc->s.loop_ms[1]; }
+    return 0;
 }
 
 // One-time work a first render would otherwise do inside its call: flatten, upload the tables for the chosen precision,
@@ -776,6 +832,14 @@ int rt_scene_prepare(rt_scene* sc, uint32_t flags) {
 
 } // extern "C"
 namespace rt {
+// what the synchronous multi-GPU entry point (rt_render_multi) does before it enqueues its frame: the implicit calibration of a first large frame
+int calibrate_if_worth_it(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+                          uint64_t seed, uint32_t flags) {
+    if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
+    if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    return calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, nullptr, true);
+}
 // rt_scene_prepare's work for one device context; the calling thread's current HIP device must be c.device and the scene must be
 // flattened.  Touches only `c` and reads s.flat, so rt_render_multi may run it for several devices from several threads at once.
 int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
@@ -787,7 +851,7 @@ int prepare_device(Scene& s, Scene::DeviceCtx& c, uint32_t flags) {
         if (!l.ev_start) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_start = e; }
         if (!l.ev_stop) { hipEvent_t e; HIP_OK(hipEventCreate(&e)); l.ev_stop = e; }
     }
-    const uint32_t eff = effective_flags(s.flat, flags, s.loop_choice);
+    const uint32_t eff = effective_flags(s.flat, flags, s.loop_how == 4 ? s.loop_choice : -1);
     const LaunchShape shape = pathtrace_shape(s.flat.feats, eff);
     hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, c.device));
     int bpc;
@@ -925,7 +989,7 @@ int rt_render_samples(rt_scene* sc, const rt_camera* cam, const double bg[3], ui
         hipError_t e = hipMalloc(&d_samples, n_px * spp * 3 * sizeof(double));
         if (e != hipSuccess) { (void)hipFree(d_out); return set_err(std::string("hipMalloc(samples): ") + hipGetErrorString(e)); }
     }
-    int rc = render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, (uint32_t)n_px, 0, 1, d_out, n_px * 3 * sizeof(double), d_samples, nullptr);
+    int rc = render_any(sc, cam, bg, W, H, spp, max_depth, seed, flags, (uint32_t)n_px, 0, 1, d_out, n_px * 3 * sizeof(double), d_samples, nullptr, true);
     if (rc == 0) {
         hipError_t e = hipStreamSynchronize(nullptr);
         if (e == hipSuccess) e = hipMemcpy(rgb_sum_out, d_out, n_px * 3 * sizeof(double), hipMemcpyDeviceToHost);

@@ -2065,6 +2065,10 @@ template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t
 LaunchShape pathtrace_shape(uint32_t scene_feats, uint32_t flags) {
     return dispatch<double>(scene_feats, flags, [&]() { return shape_lean(); }, [&](auto feats) { return shape_one<decltype(feats)::value>(); });
 }
+// the FEATS template argument of the instantiation that serves (scene_feats, flags): the kernel's name is pathtrace_kernel<T, that>
+uint32_t pathtrace_feats(uint32_t scene_feats, uint32_t flags) {
+    return dispatch<double>(scene_feats, flags, [&]() { return FEATS_LEAN; }, [&](auto feats) { return (uint32_t) decltype(feats)::value; });
+}
 
 template hipError_t launch_pathtrace<double>(const KParams<double>&, uint32_t, uint32_t, size_t, hipStream_t);
 template hipError_t launch_pathtrace<float>(const KParams<float>&, uint32_t, uint32_t, size_t, hipStream_t);

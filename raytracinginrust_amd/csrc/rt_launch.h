@@ -8,6 +8,7 @@ namespace rt {
 // it runs as ONE workgroup per CU (BVH kernels: the CU's LDS then holds one copy of the top of the BVH, KParams::n_cached nodes).
 struct LaunchShape { uint32_t threads, queue_entries; bool one_per_cu; };
 LaunchShape pathtrace_shape(uint32_t scene_feats, uint32_t flags);
+uint32_t pathtrace_feats(uint32_t scene_feats, uint32_t flags);      // the instantiation's FEATS template argument (its name: rt::pathtrace_kernel<T, FEATSu>)
 // Dynamic LDS of one workgroup: [n_cached nodes][waves x queue][waves x stack_depth x 64 dwords]
 inline size_t pathtrace_lds_bytes(const LaunchShape& g, uint32_t stack_depth, uint32_t n_cached, size_t node_bytes) {
     const size_t waves = g.threads / 64u;

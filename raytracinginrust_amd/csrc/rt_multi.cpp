@@ -369,7 +369,20 @@ int rt_multi_copy_frame(rt_scene* sc, double* rgb_sum_out, size_t n_doubles) {
 
 int rt_render_multi(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                     uint64_t seed, uint32_t flags, uint32_t device_mask, uint32_t tile_px, double* rgb_sum_out) {
-    if (!rgb_sum_out) return set_error("null argument");
+    if (!rgb_sum_out || !sc || !cam || !bg) return set_error("null argument");
+    {   // this entry point is synchronous: a first large frame of a mesh scene measures its loop shape here (rt_host.cpp:
+        // calibrate_loop_shape), on the frame's first device; the asynchronous rt_render_multi_device never does
+        const int n_visible = rt_device_count();
+        int first = -1;
+        for (int d = 0; d < n_visible && d < 32 && first < 0; d++) if (device_mask == 0u || (device_mask >> d) & 1u) first = d;
+        if (first >= 0) {
+            int cur = 0; (void)hipGetDevice(&cur);
+            (void)hipSetDevice(first);
+            const int rc = rt::calibrate_if_worth_it(sc, cam, bg, W, H, spp, max_depth, seed, flags & ~(uint32_t)RT_MULTI_COLLECTIVE);
+            (void)hipSetDevice(cur);
+            if (rc) return -1;
+        }
+    }
     if (rt_render_multi_device(sc, cam, bg, W, H, spp, max_depth, seed, flags, device_mask, tile_px, nullptr)) return -1;
     const double t0 = sc->s.multi_t0;
     if (rt_multi_copy_frame(sc, rgb_sum_out, (size_t)W * H * 3)) return -1;

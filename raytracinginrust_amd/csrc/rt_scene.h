@@ -57,8 +57,19 @@ struct Scene {
     int world = -1;
     unsigned trav_hi = 56, trav_lo = 16, trav_leaf = 32;      // persistent-traversal schedule (rt_scene_set_traversal_schedule); measured best on the teapot room (round 5, the filtered walk: profiles/r05_trav_schedule_sweep.log; 40 / 24 / 24 before)
     int bvh_builder = 0;      // 0: the reference's widest-axis object-median split (bvh.rs:18-73); 1: binned SAH (opt-in)
-    int loop_choice = -1;     // mesh scenes: which loop shape a calibration render found faster for THIS scene and view (1 persistent traversal,
-                              // 0 lock-step; -1 not measured: the size rule decides) — rt_host.cpp: calibrate_loop_shape; same samples either way
+    // Mesh scenes: which loop shape (1 persistent traversal, 0 lock-step; -1: the size rule decides) — same samples either way.  Set by a
+    // calibration (rt_scene_calibrate, or the first large frame of a SYNCHRONOUS entry point: rt_host.cpp calibrate_loop_shape), which is
+    // valid for the view it measured (loop_key: camera, frame size, precision — another view falls back to the size rule until it is
+    // calibrated itself), or by rt_scene_set_loop_shape (any view, until the scene changes: how a launcher hands rank 0's choice to the others).
+    int loop_choice = -1;
+    int loop_how = 0;         // 0 nothing stored, 2 calibration (keyed), 4 rt_scene_set_loop_shape (not keyed)
+    unsigned long long loop_key = 0;
+    float loop_ms[2] = {0.f, 0.f};     // the calibration's kernel times: [0] lock-step, [1] persistent traversal (ms; 0: not measured)
+    void* d_calib = nullptr; size_t calib_bytes = 0; int calib_device = -1;     // the calibration renders' frame buffer, kept with the scene
+    // what the most recent launch ran (rt_last_loop_info): [0] loop shape (0 list kernel, 1 lock-step BVH, 2 persistent traversal), [1] the
+    // FEATS template argument of the instantiation, [2] how the shape was chosen (0 the scene leaves no choice, 1 size rule, 2 calibration,
+    // 3 the caller's RT_PERSISTENT_BVH / RT_LOCKSTEP_BVH flag, 4 rt_scene_set_loop_shape), [3] precision (0 f64, 1 f32)
+    int last_loop[4] = {0, 0, 0, 0};
     std::vector<int> lights;
     std::string error;
 
@@ -117,7 +128,7 @@ struct Scene {
     // debugging aid (rt_debug_trace_path; -DRT_TRACE_PATH builds of the kernels): the path whose hits are recorded, and the device buffer
     long long trace_px = -1, trace_s = -1; void* d_trace = nullptr; int trace_device = -1; uint32_t trace_levels = 0;     // trace_levels: 16-double records d_trace holds
 
-    void invalidate() { flat_valid = false; loop_choice = -1; }
+    void invalidate() { flat_valid = false; loop_choice = -1; loop_how = 0; loop_ms[0] = loop_ms[1] = 0.f; }
     DeviceCtx& ctx_for(int device) {
         for (DeviceCtx* c : ctxs) if (c->device == device) return *c;
         DeviceCtx* c = new DeviceCtx(); c->device = device; ctxs.push_back(c); return *c;
@@ -141,3 +152,7 @@ void camera_new(const rt_camera_args& a, DCamera<double>& out);
 } // namespace rt
 
 struct rt_scene { rt::Scene s; };       // the opaque handle of include/rt_amd.h
+struct rt_camera;
+namespace rt {
+int calibrate_if_worth_it(::rt_scene* sc, const ::rt_camera* cam, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth, uint64_t seed, uint32_t flags);   // rt_render_multi: the implicit loop-shape calibration of a first large frame (current device = the frame's first)
+}

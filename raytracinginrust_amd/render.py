@@ -65,6 +65,45 @@ def prepare(b: SceneBuilder, flags: int = RT_F64) -> None:
         raise RenderError(_err(be))
 
 
+LOOP_SHAPES = ("list", "lock-step", "persistent")
+LOOP_CHOSEN_BY = ("the scene leaves no choice", "size rule", "calibration of this view", "caller's flag", "rt_scene_set_loop_shape")
+
+
+def calibrate(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int,
+              seed: int = 0x5EED, flags: int = RT_F64) -> None:
+    """rt_scene_calibrate: mesh scenes measure now, synchronously, which loop shape is faster for this view (four small launches);
+    a no-op for every other scene.  The asynchronous entry points (render_tiles_device, render_multi_device) never do it themselves."""
+    be = _lib.load()
+    bg = (C.c_double * 3)(*[float(x) for x in background])
+    if be.lib.rt_scene_calibrate(b.h, C.byref(cam), bg, W, H, spp, max_depth, seed, flags) != 0:
+        raise RenderError(_err(be))
+
+
+def set_loop_shape(b: SceneBuilder, shape: int) -> None:
+    """rt_scene_set_loop_shape: 1 persistent traversal, 0 lock-step (every view, until the scene changes), -1 forget."""
+    be = _lib.load()
+    if be.lib.rt_scene_set_loop_shape(b.h, shape) != 0:
+        raise RenderError(_err(be))
+
+
+def stored_loop_shape(b: SceneBuilder) -> int:
+    """rt_scene_loop_shape: 1 persistent traversal, 0 lock-step, -1 nothing stored."""
+    return int(_lib.load().lib.rt_scene_loop_shape(b.h))
+
+
+def last_loop_info(b: SceneBuilder) -> dict:
+    """rt_last_loop_info: the loop shape and instantiation the most recent launch ran, how the shape was chosen, and the stored
+    calibration's kernel times."""
+    be = _lib.load()
+    out = (C.c_int32 * 4)(); ms = (C.c_float * 2)()
+    if be.lib.rt_last_loop_info(b.h, out, ms) != 0:
+        raise RenderError(_err(be))
+    t = "float" if out[3] else "double"
+    return {"shape": LOOP_SHAPES[out[0]], "feats": int(out[1]), "kernel": f"rt::pathtrace_kernel<{t}, {int(out[1])}u>",
+            "chosen_by": LOOP_CHOSEN_BY[out[2]],
+            "calibration_ms": {"lock-step": float(ms[0]), "persistent": float(ms[1])} if ms[0] > 0 or ms[1] > 0 else None}
+
+
 def render(b: SceneBuilder, cam: CameraParams, background, W: int, H: int, spp: int, max_depth: int,
            seed: int = 0x5EED, flags: int = RT_F64, want_samples: bool = False):
     """Per-pixel sums of ray_color over `spp` samples, shape (H, W, 3) f64, row 0 = top (what `.sum()`

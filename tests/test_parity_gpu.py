@@ -779,36 +779,63 @@ def _cloud_room(be, n_tris, radius):
 def test_loop_shape_of_a_mesh_scene_is_measured(pbe, monkeypatch):
     """Mesh scenes run a persistent-traversal or a lock-step loop — same samples, and which is faster depends on the view, not on the
     tree's size (round 5: the teapot room's 2047-node tree prefers the persistent loop by 10 %, a 1999-node cloud of triangles the
-    lock-step loop by 10 %).  The first render of a frame of >= 1e8 samples measures both on a smaller copy of the view and keeps the
-    faster (rt_host.cpp: calibrate_loop_shape); small frames and RT_NO_LOOP_CALIBRATION keep the size rule."""
+    lock-step loop by 10 %).  A calibration (rt_host.cpp: calibrate_loop_shape) measures both on a smaller copy of the view and keeps the
+    faster FOR THAT VIEW: rt_scene_calibrate, or the first frame of >= 1e8 samples through a synchronous entry point; the asynchronous
+    entry points never calibrate; small frames, other views and RT_NO_LOOP_CALIBRATION keep the size rule; rt_scene_set_loop_shape
+    overrides everything; rt_last_loop_info says what ran and why.  (Functional assertions only: which shape is faster on the day is
+    tools/mesh_size_probe.py's business, not a test's.)"""
     W, H, spp, depth = 1024, 1024, 256, 50
     for make in (lambda: scenes.cornell_test(pbe, scenes.asset_path("teapot.obj")), lambda: _cloud_room(pbe, 1000, 70.0)):
-        b, cam, bg = make()
-        t = {}
-        for name, fl in (("lock", R.RT_LOCKSTEP_BVH), ("pers", R.RT_PERSISTENT_BVH)):
-            ms = []
-            for _ in range(3):
-                R.render(b, cam, bg, W, H, spp, depth, flags=fl); ms.append(R.last_kernel_ms(b))
-            t[name] = min(ms)
         b2, cam2, bg2 = make()                                     # a fresh scene: nothing measured yet
         _, auto = R.render(b2, cam2, bg2, 96, 96, 4, depth, want_samples=True)            # a small frame first: no calibration, the size rule (persistent: >= 640 nodes)
-        assert R.last_traversal_stats(b2)["traversal_steps"] > 0
-        ms = []
+        li = R.last_loop_info(b2)
+        assert li["shape"] == "persistent" and li["chosen_by"] == "size rule" and li["calibration_ms"] is None and li["feats"] == 261
+        assert li["kernel"] == "rt::pathtrace_kernel<double, 261u>" and R.last_traversal_stats(b2)["traversal_steps"] > 0
         for _ in range(3):
-            R.render(b2, cam2, bg2, W, H, spp, depth); ms.append(R.last_kernel_ms(b2))
-        chose_pers = R.last_traversal_stats(b2)["traversal_steps"] > 0
-        assert min(ms) <= 1.04 * min(t.values()), (t, ms)
-        if abs(t["pers"] - t["lock"]) > 0.06 * min(t.values()):
-            assert chose_pers == (t["pers"] < t["lock"]), (t, chose_pers)
+            R.render(b2, cam2, bg2, W, H, spp, depth)              # the first of them measures the view (synchronous entry point, 2.7e8 samples)
+        li = R.last_loop_info(b2)
+        ms = li["calibration_ms"]
+        assert li["chosen_by"] == "calibration of this view" and ms["lock-step"] > 0 and ms["persistent"] > 0
+        if abs(ms["persistent"] - ms["lock-step"]) > 0.03 * min(ms.values()):             # the stored numbers decide, reproducibly
+            assert (li["shape"] == "persistent") == (ms["persistent"] < ms["lock-step"]), li
+        assert (li["shape"] == "persistent") == (R.last_traversal_stats(b2)["traversal_steps"] > 0) and R.stored_loop_shape(b2) in (0, 1)
         total_ms, n = R.kernel_time_total(b2)
         assert n == 4                                               # the calibration launches are not in the caller's totals
+        # the calibration belongs to the view it measured: another frame size is the size rule's again
         _, lock = R.render(b2, cam2, bg2, 96, 96, 4, depth, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
+        assert R.last_loop_info(b2)["chosen_by"] == "caller's flag" and R.last_loop_info(b2)["shape"] == "lock-step" and R.last_loop_info(b2)["feats"] == 5
         assert np.array_equal(auto.view(np.uint64), lock.view(np.uint64))
+        R.render(b2, cam2, bg2, 96, 96, 4, depth)
+        assert R.last_loop_info(b2)["chosen_by"] == "size rule"
+        # a set shape serves every view; -1 forgets it (and the calibration)
+        R.set_loop_shape(b2, 0)
+        _, forced = R.render(b2, cam2, bg2, 96, 96, 4, depth, want_samples=True)
+        li = R.last_loop_info(b2)
+        assert li["shape"] == "lock-step" and li["chosen_by"] == "rt_scene_set_loop_shape" and np.array_equal(auto.view(np.uint64), forced.view(np.uint64))
+        R.set_loop_shape(b2, -1)
+        assert R.stored_loop_shape(b2) == -1
         monkeypatch.setenv("RT_NO_LOOP_CALIBRATION", "1")
         b3, cam3, bg3 = make()
         R.render(b3, cam3, bg3, W, H, spp, depth)
         assert R.last_traversal_stats(b3)["traversal_steps"] > 0    # the size rule: 1999 / 2047 nodes >= 640
+        assert R.last_loop_info(b3)["chosen_by"] == "size rule"
         monkeypatch.delenv("RT_NO_LOOP_CALIBRATION")
+        # the asynchronous entry points never measure: a fresh scene's large frame through rt_render_multi_device is the size rule's ...
+        b4, cam4, bg4 = make()
+        R.render_multi_device(b4, cam4, bg4, W, H, spp, depth, device_mask=1); R.multi_sync(b4)
+        assert R.last_loop_info(b4)["chosen_by"] == "size rule" and R.kernel_time_total(b4)[1] == 1
+        # ... until the caller calibrates the view (explicitly, synchronously): then they run what it found
+        R.calibrate(b4, cam4, bg4, W, H, spp, depth)
+        assert R.kernel_time_total(b4)[1] == 1                      # (its four launches stay out of the totals)
+        R.render_multi_device(b4, cam4, bg4, W, H, spp, depth, device_mask=1); R.multi_sync(b4)
+        li4 = R.last_loop_info(b4)
+        assert li4["chosen_by"] == "calibration of this view" and li4["calibration_ms"]["persistent"] > 0
+    # a scene whose loop shape is not open: nothing to measure, nothing stored
+    b5, cam5, bg5 = scenes.cornell_box(pbe)
+    R.calibrate(b5, cam5, bg5, W, H, spp, depth)
+    R.render(b5, cam5, bg5, 64, 64, 4, depth)
+    li5 = R.last_loop_info(b5)
+    assert li5 == {"shape": "list", "feats": 0, "kernel": "rt::pathtrace_kernel<double, 0u>", "chosen_by": "the scene leaves no choice", "calibration_ms": None}
 
 
 def _big_mesh_room(be, n_tris):
@@ -895,7 +922,7 @@ def test_box_filter_is_conservative_on_grazing_rays(pbe):
     assert not culled.any(), f"the f32 filter culled {int(culled.sum())} boxes AABB::hit passes, e.g. case {int(np.flatnonzero(culled)[0])}"
 
 
-def test_cube_fast_path_against_the_six_rect_tests(pbe):
+def test_cube_fast_path_against_the_six_rect_tests(pbe, obe):
     """Cube::hit on the device two ways (rt_debug_cube_hit): the reference's six AARect tests in cube.rs:17-24 order under HittableList::hit,
     and the kernels' fast path (rt_kernel.hip: cube_fast — six approximate plane distances, ONE exact rect test for the face that wins).
     Wherever the fast path declares a case CLEAR its answer must be the six tests' answer bit for bit: the same t, the same face, or
@@ -956,6 +983,14 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe):
     bad = clear & ((face_fast != face_ref) | (t_fast.view(np.uint64) != t_ref.view(np.uint64)) & ~(np.isnan(t_fast) & np.isnan(t_ref)))
     assert not bad.any(), f"{int(bad.sum())} clear cases differ from the six rect tests, e.g. case {int(np.flatnonzero(bad)[0])}: " \
                           f"ref (t {t_ref[np.flatnonzero(bad)[0]]!r}, face {face_ref[np.flatnonzero(bad)[0]]}) fast (t {t_fast[np.flatnonzero(bad)[0]]!r}, face {face_fast[np.flatnonzero(bad)[0]]})"
+    # ... and the device's six-test side IS the reference's Cube::hit: the oracle's (cube.rs:14-37 over rect.rs:49-60), same t bit for
+    # bit, same face, on every one of the cases (round 6: until then the known-answer test was device against device)
+    ref2 = np.zeros((n, 2))
+    obe.lib.orc_cube_hit_batch(n, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, ref2.ctypes.data)
+    t_orc, face_orc = ref2[:, 0], ref2[:, 1].astype(int)
+    assert (face_orc >= -1).all()
+    differ = (face_orc != face_ref) | ((t_orc.view(np.uint64) != t_ref.view(np.uint64)) & ~(np.isnan(t_orc) & np.isnan(t_ref)))
+    assert not differ.any(), f"{int(differ.sum())} cases: the device's six rect tests differ from the oracle's Cube::hit, e.g. case {int(np.flatnonzero(differ)[0])}"
     # the same cubes with the scene-wide bound far larger than their own coordinates (other rects of the scene): still exact
     assert lib.rt_debug_cube_hit(n, rect_m * 1000.0, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, out.ctypes.data) == 0
     clear2 = (out[:, 3].astype(int) & 8) != 0

@@ -9,10 +9,10 @@ import re
 
 from conftest import ROOT
 
-C_SCALARS = {"double": "f64", "int": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "uint8_t": "u8", "char": "char",
+C_SCALARS = {"double": "f64", "int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "size_t": "usize", "uint8_t": "u8", "char": "char",
              "float": "f32", "void": "void", "rt_scene": "Scene", "rt_rng": "Rng", "rt_camera": "Camera", "long long": "i64",
              "unsigned long long": "u64"}
-RUST_SCALARS = {"c_double": "f64", "c_int": "i32", "u32": "u32", "u64": "u64", "usize": "usize", "u8": "u8", "c_char": "char",
+RUST_SCALARS = {"c_double": "f64", "c_int": "i32", "i32": "i32", "f32": "f32", "u32": "u32", "u64": "u64", "usize": "usize", "u8": "u8", "c_char": "char",
                 "c_float": "f32", "c_void": "void", "RtScene": "Scene", "RtRng": "Rng", "RtCamera": "Camera", "i64": "i64"}
 
 

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box: PMC passes for the bench workload (each pass = its own rocprofv3 run; no trace domains
-# are combined with --pmc).  Usage: tools/profile_pmc.sh <tag> [bench args...]
+# are combined with --pmc).  Usage: tools/profile_pmc.sh <tag> [bench args...]   (for a mesh workload pass --loop persistent|lockstep:
+# tools/profile_all.sh does, after asking an un-profiled call which one the scene runs)
 set -u
 TAG=${1:-r01}; shift || true
 OUT=/root/repo/gpurun_out/pmc_$TAG
