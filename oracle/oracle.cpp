@@ -1406,7 +1406,7 @@ void orc_cube_hit_batch(uint32_t n, const double* boxes, const double* rays, con
         if (any) {      // the same scan as HittableList::hit, keeping the index of the item whose record was kept
             double closest = tlim[2 * i + 1]; HitRecord t2; int k = 0;
             for (const Hittable* side : c.sides.list) { if (side->hit(r, tlim[2 * i], closest, tmp, t2)) { closest = t2.t; face = k; } k++; }
-            if (!(closest == rec.t)) face = -2;      // (cannot happen: the two scans are the same code)
+            if (!(closest == rec.t) && !(closest != closest && rec.t != rec.t)) face = -2;      // (cannot happen: the two scans are the same code; a 0 / 0 plane distance is a NaN hit in both)
         }
         out[2 * i] = any ? rec.t : double(std::nan(""));
         out[2 * i + 1] = (double)face;

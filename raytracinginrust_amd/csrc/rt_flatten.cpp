@@ -24,6 +24,11 @@ struct Flattener {
     HostFlat& f;
     std::map<int, uint32_t> prim_of_node;   // node id -> first primitive index in its pool (emitted once, shared)
     std::string err;
+    // the wrappers an object stands in, outermost first; n_outer of them lie outside the BVH whose leaf the object is (0 at the top
+    // level), med_at of them outside its ConstantMedium (-1: no medium met yet)
+    struct Chain { DOp<double> ops[RT_MAX_OPS]; int n = 0; int n_outer = 0; int med_at = -1; };
+    std::vector<DObject> subs;              // sub-objects of G_OBJ leaves, appended to f.objects behind the world's own once the world is done
+    std::vector<DObject>* target = nullptr; // where emit_object puts an object: f.objects (the world list) or subs
     explicit Flattener(Scene& sc) : s(sc), f(sc.flat) {}
 
     bool fail(const std::string& m) { if (err.empty()) err = m; return false; }
@@ -127,21 +132,63 @@ struct Flattener {
                 b.mx[k] = std::fmax(h.v[k], std::fmax(h.v[3 + k], h.v[6 + k]));
             }
             return true;
-        default:
-            return false;
+        case HNode::LIST: {       // hit.rs:73-88: the first item's box, then surrounding_box over the rest; None for an empty list or a box-less item
+            if (h.items.empty() || !bbox(h.items[0], b)) return false;
+            for (size_t i = 1; i < h.items.size(); i++) { Box o; if (!bbox(h.items[i], o)) return false; surround(b, o); }
+            return true;
         }
+        case HNode::FLIP: case HNode::MEDIUM:      // hit.rs:122-124, medium.rs:63-65
+            return bbox(h.child, b);
+        case HNode::TRANSLATE:                     // translate.rs:32-40
+            if (!bbox(h.child, b)) return false;
+            for (int k = 0; k < 3; k++) { b.mn[k] += h.v[k]; b.mx[k] += h.v[k]; }
+            return true;
+        case HNode::ROTATE: {                      // rotate.rs:37-66 (Rotate::new): min starts at f64::MIN, max at f64::MAX, with `<` / `>` updates that
+            Box c;                                 // fire only for an infinite corner — the box is all of space (reference quirk B3), reproduced as computed
+            if (!bbox(h.child, c)) return false;
+            const double radiants = (3.14159265358979323846264338327950288 / 180.0) * h.v[0];
+            double sn, cs; ::sincos(radiants, &sn, &cs);
+            const int ax = h.plane_or_axis;
+            const int r_axis = ax == 0 ? 0 : (ax == 1 ? 1 : 2), a_axis = ax == 0 ? 1 : 0, b_axis = ax == 2 ? 1 : 2;      // rotate.rs:14-20
+            for (int k = 0; k < 3; k++) { b.mn[k] = -F64_MAX; b.mx[k] = F64_MAX; }
+            for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+                const double r = (double)k * c.mx[r_axis] + (double)(1 - k) * c.mn[r_axis];
+                const double a = (double)i * c.mx[a_axis] + (double)(1 - i) * c.mn[a_axis];
+                const double bb = (double)j * c.mx[b_axis] + (double)(1 - j) * c.mn[b_axis];
+                const double new_a = cs * a + sn * bb;
+                const double new_b = -sn * a + cs * bb;
+                if (new_a < b.mn[a_axis]) b.mn[a_axis] = new_a;
+                if (new_b < b.mn[b_axis]) b.mn[b_axis] = new_b;
+                if (r < b.mn[r_axis]) b.mn[r_axis] = r;
+                if (new_a > b.mx[a_axis]) b.mx[a_axis] = new_a;
+                if (new_b > b.mx[b_axis]) b.mx[b_axis] = new_b;
+                if (r > b.mx[r_axis]) b.mx[r_axis] = r;
+            }
+            return true;
+        }
+        case HNode::BVH: {        // bvh.rs:93-95: the root's box = surrounding_box folded over the tree (min / max: the same for every tree shape)
+            if (h.items.empty() || !bbox(h.items[0], b)) return false;
+            for (size_t i = 1; i < h.items.size(); i++) { Box o; if (!bbox(h.items[i], o)) return false; surround(b, o); }
+            return true;
+        }
+        }
+        return false;
     }
+    static void surround(Box& b, const Box& o) { for (int k = 0; k < 3; k++) { b.mn[k] = std::fmin(b.mn[k], o.mn[k]); b.mx[k] = std::fmax(b.mx[k], o.mx[k]); } }   // aabb.rs:40-51
 
     // ---- BVH::new, src/bvh.rs:18-73.  Emits nodes in DFS preorder (left child = parent + 1); relayout_bvh_by_depth() below then
     // renumbers them by depth and stores both children.
     // `sort_unstable_by` leaves ties unspecified; a stable sort is used (tie order changes cost, never results).
-    bool build_bvh(std::vector<int> items, uint32_t depth, uint32_t& out_index, Box& out_box) {
+    // A child that is not a bare primitive / Cube (bvh.rs:18 takes any Box<dyn Hittable>) becomes a leaf of kind G_OBJ: the run of sub-objects
+    // it flattens to under the chain of wrappers the BVH itself stands in (`chain`: each sub-object carries the whole chain from the world
+    // down, the first chain.n ops of which lie outside this BVH).  `nest`: how many BVHs this one is inside of.
+    bool build_bvh(std::vector<int> items, uint32_t depth, uint32_t& out_index, Box& out_box, const Chain& chain, int nest) {
         if (items.empty()) return fail("no object in the scene");                    // bvh.rs:55
         if (depth > (uint32_t)RT_MAX_BVH_DEPTH) return fail("BVH deeper than RT_MAX_BVH_DEPTH");
         f.bvh_depth = std::max(f.bvh_depth, depth);
         std::vector<Box> boxes(items.size());
         for (size_t i = 0; i < items.size(); i++)
-            if (!bbox(items[i], boxes[i])) return fail("unsupported BVH child (only Sphere, MovingSphere, AARect, Cube, Triangle have device leaf forms)");
+            if (!bbox(items[i], boxes[i])) return fail("no bounding box in bvh node");                 // bvh.rs:28,61 panic (an empty list, or a wrapper of one)
         int axis = 0; double best = 0;
         for (int a = 0; a < 3; a++) {                                                 // bvh.rs:33-48
             double mn = F64_MAX, mx = -F64_MAX;
@@ -209,7 +256,19 @@ struct Flattener {
         size_t length = items.size();
         if (length == 1) {
             uint32_t kind, first, count;
-            if (!simple_geom(items[0], kind, first, count)) return fail("unsupported BVH child");
+            if (!simple_geom(items[0], kind, first, count)) {
+                // any other Hittable: the sub-objects it flattens to (a list may give several: HittableList::hit over them, hit.rs:59-71)
+                std::vector<DObject>* const saved = target;
+                target = &subs;
+                const size_t s0 = subs.size();
+                Chain c2 = chain; c2.n_outer = chain.n; c2.med_at = -1;
+                const bool ok = emit(items[0], c2, -1, nest + 1);
+                target = saved;
+                if (!ok) return false;
+                kind = G_OBJ; first = (uint32_t)s0; count = (uint32_t)(subs.size() - s0);
+                f.feats |= F_NESTED;
+                // (count == 0 cannot be reached: a child without sub-objects is an empty list, which has no bounding box)
+            }
             if (first >= (1u << 28)) return fail("too many primitives");
             out_box = boxes[0];
             DBvhNode<double>& nd = f.bvh[me];
@@ -222,8 +281,8 @@ struct Flattener {
         for (size_t i = 0; i < n_lower; i++) lower.push_back(items[order[i]]);
         for (size_t i = n_lower; i < length; i++) upper.push_back(items[order[i]]);      // bvh.rs:65: drain(length/2..) -> right
         uint32_t li, ri; Box lb, rb;
-        if (!build_bvh(lower, depth + 1, li, lb)) return false;
-        if (!build_bvh(upper, depth + 1, ri, rb)) return false;
+        if (!build_bvh(lower, depth + 1, li, lb, chain, nest)) return false;
+        if (!build_bvh(upper, depth + 1, ri, rb, chain, nest)) return false;
         for (int k = 0; k < 3; k++) { out_box.mn[k] = std::fmin(lb.mn[k], rb.mn[k]); out_box.mx[k] = std::fmax(lb.mx[k], rb.mx[k]); }   // aabb.rs:40-51
         DBvhNode<double>& nd = f.bvh[me];
         for (int k = 0; k < 3; k++) { nd.mn[k] = out_box.mn[k]; nd.mx[k] = out_box.mx[k]; }
@@ -234,18 +293,19 @@ struct Flattener {
     }
 
     // ---- world flattening
-    struct Chain { DOp<double> ops[RT_MAX_OPS]; int n = 0; };
-
     bool emit_object(uint32_t kind, uint32_t first, uint32_t count, const Chain& chain, int medium, bool is_cube = false) {
         DObject o{};
         o.geom_kind = kind; o.geom_first = first; o.geom_count = count; o.is_cube = is_cube ? 1u : 0u;
         o.first_op = (uint32_t)f.ops.size(); o.n_ops = (uint32_t)chain.n; o.medium = medium;
+        const int med_at = medium >= 0 ? chain.med_at : 0;
+        o.nest = (uint32_t)chain.n_outer | ((uint32_t)med_at << 8);
+        if (med_at != 0) f.feats |= F_NESTED;          // a ConstantMedium under a wrapper: the all-features kernel's object_hit serves it
         for (int i = 0; i < chain.n; i++) f.ops.push_back(chain.ops[i]);
-        f.objects.push_back(o);
+        target->push_back(o);
         return true;
     }
 
-    bool emit(int n, const Chain& chain, int medium) {
+    bool emit(int n, const Chain& chain, int medium, int nest = 0) {
         if (n < 0 || n >= (int)s.nodes.size()) return fail("bad hittable handle");
         const HNode& h = s.nodes[n];
         uint32_t kind, first, count;
@@ -282,7 +342,7 @@ struct Flattener {
                     i = j;
                 } else {
                     if (medium >= 0 && (emitted_any || h.items.size() != 1)) return fail("ConstantMedium boundary must flatten to one object");
-                    if (!emit(h.items[i], chain, medium)) return false;
+                    if (!emit(h.items[i], chain, medium, nest)) return false;
                     emitted_any = true;
                     i++;
                 }
@@ -308,22 +368,23 @@ struct Flattener {
                 double sn, cs; ::sincos(radiants, &sn, &cs);
                 op.x = sn; op.y = cs;
             }
-            return emit(h.child, c2, medium);
+            return emit(h.child, c2, medium, nest);
         }
         case HNode::MEDIUM: {
             if (medium >= 0) return fail("nested ConstantMedium is not supported");
-            if (chain.n != 0) return fail("ConstantMedium inside Translate/Rotate/FlipNormal is not supported (make it the outermost wrapper)");
             // Isotropic::new(texture), medium.rs:21
             DMaterial<double> iso{}; iso.kind = M_ISOTROPIC; iso.tex = (uint32_t)h.mat;
             f.materials.push_back(iso);
             DMedium<double> m{}; m.neg_inv_density = -(1.0 / h.v[0]); m.mat = (uint32_t)f.materials.size() - 1;
             f.media.push_back(m);
             f.feats |= F_MEDIUM;
-            return emit(h.child, chain, (int)f.media.size() - 1);
+            Chain c2 = chain; c2.med_at = chain.n;      // the wrappers met so far lie outside the medium
+            return emit(h.child, c2, (int)f.media.size() - 1, nest);
         }
         case HNode::BVH: {
+            if (nest > RT_MAX_NEST) return fail("BVHs nested more than RT_MAX_NEST deep inside BVH leaves");
             uint32_t root; Box b;
-            if (!build_bvh(h.items, 1, root, b)) return false;
+            if (!build_bvh(h.items, 1, root, b, chain, nest)) return false;
             f.feats |= F_BVH;
             return emit_object(G_BVH, root, 1, chain, medium);
         }
@@ -344,7 +405,19 @@ struct Flattener {
                 for (int k = 0; k < 3; k++) m.albedo[k] = f.textures[m.tex].color[k];
         if (s.world < 0) return fail("world not set");
         Chain c;
+        target = &f.objects;
         if (!emit(s.world, c, -1)) return false;
+        // the sub-objects follow the world's own objects in the one table: G_OBJ leaves learn their final indices
+        f.n_top = (uint32_t)f.objects.size();
+        if (!subs.empty()) {
+            for (DBvhNode<double>& nd : f.bvh)
+                if ((nd.a & BVH_LEAF) && ((nd.a >> 28) & 7u) == G_OBJ) {
+                    const uint32_t first = (nd.a & 0x0FFFFFFFu) + f.n_top;
+                    if (first >= (1u << 28)) return fail("too many objects");
+                    nd.a = BVH_LEAF | (G_OBJ << 28) | first;
+                }
+            f.objects.insert(f.objects.end(), subs.begin(), subs.end());
+        }
         // which materials' textures read (u, v): ImageTexture, possibly under CheckTextures (texture.rs:45-54)
         {
             std::vector<int> uv(f.textures.size(), -1);          // -1 unknown, 0 / 1 known

@@ -518,9 +518,9 @@ static uint32_t stack_depth_of(const HostFlat& f, uint32_t effective) { return (
 static bool loop_shape_is_open(const HostFlat& f, uint32_t flags, size_t* n_bvh_objects_out = nullptr) {
     if ((flags & (RT_PERSISTENT_BVH | RT_LOCKSTEP_BVH)) || !(f.feats & F_BVH) || (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u) return false;
     size_t n_bvh_objects = 0;
-    for (const DObject& ob : f.objects) n_bvh_objects += ob.geom_kind == G_BVH ? 1u : 0u;
+    for (uint32_t i = 0; i < f.n_top; i++) n_bvh_objects += f.objects[i].geom_kind == G_BVH ? 1u : 0u;
     if (n_bvh_objects_out) *n_bvh_objects_out = n_bvh_objects;
-    return n_bvh_objects != 0 && n_bvh_objects < f.objects.size();
+    return n_bvh_objects != 0 && n_bvh_objects < f.n_top;
 }
 static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choice = -1, int* how_out = nullptr) {
     uint32_t out = flags;
@@ -538,11 +538,14 @@ static uint32_t effective_flags(const HostFlat& f, uint32_t flags, int loop_choi
         if (loop_choice >= 0 ? loop_choice == 1 : by_size) out |= RT_PERSISTENT_BVH;
     }
     if (flags & RT_LOCKSTEP_BVH) out &= ~(uint32_t)RT_PERSISTENT_BVH;
+    // BVHs with object leaves (any Hittable as a BVH child) are served by one instantiation: the reference's order, the lock-step loop
+    // (the nearer-first order is an opt-in with the same closest hits; a walk inside a walk would need a second LDS stack for it)
+    if (f.feats & F_NESTED) out &= ~(uint32_t)(RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH);
     // Speculative box steps (scheduling only): for the lock-step all-features-but-PBR kernel when the world is ONE bare BVH — every ray
     // enters it, which is where walking on past an untested leaf pays (*measured* random spheres +2.6 %; scenes whose trees few lanes
     // enter lose 3 %)
     {
-        const bool one_bvh = f.objects.size() == 1 && f.objects[0].geom_kind == G_BVH && f.objects[0].medium < 0;
+        const bool one_bvh = f.n_top == 1 && f.objects[0].geom_kind == G_BVH && f.objects[0].medium < 0;
         const bool can = (f.feats & F_BVH) && !(f.feats & F_PBR) && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) != 0u &&
                          !(out & (RT_NEAR_FIRST_BVH | RT_PERSISTENT_BVH));
         if (can && one_bvh && !(flags & RT_NO_SPECULATE_BVH)) out |= RT_SPECULATE_BVH;
@@ -594,7 +597,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     const HostFlat& f = s.flat;
     KParams<T> P;
     std::memset((void*)&P, 0, sizeof(P));
-    P.objects = (const DObject*)d.objects; P.n_objects = (uint32_t)f.objects.size();
+    P.objects = (const DObject*)d.objects; P.n_objects = f.n_top;
     P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
     P.n_bvh = (uint32_t)f.bvh.size();

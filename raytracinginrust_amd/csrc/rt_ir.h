@@ -10,7 +10,8 @@
 //              a typed range of primitives (1 rect, 6 rects = Cube, n triangles = Mesh list, ...) or a BVH root
 //   BVH    = nodes of all the scene's trees ordered by depth (roots first), both children stored: the first `n_cached` ids — the top
 //            levels, where most visits go — are staged in LDS by each workgroup, the rest are fetched per lane; leaves hold a typed
-//            primitive range (a sphere, a moving sphere, a triangle, or a Cube's 6 rects) and their rank in DFS preorder
+//            primitive range (a sphere, a moving sphere, a triangle, or a Cube's 6 rects) — or, for any other Hittable BVH::new accepts
+//            (bvh.rs:18-31: a list, a wrapped object, a medium, another BVH), a run of sub-objects (G_OBJ) — and their rank in DFS preorder
 //   lights = light records (rect / sphere / "other" = trait default pdf 0, random (1,0,0))
 //
 // Records are templated on the arithmetic type: the f64 build is the reference-precision product path,
@@ -22,7 +23,7 @@
 
 namespace rt {
 
-enum GeomKind : uint32_t { G_RECT = 0, G_SPHERE = 1, G_MSPHERE = 2, G_TRI = 3, G_BVH = 4 };
+enum GeomKind : uint32_t { G_RECT = 0, G_SPHERE = 1, G_MSPHERE = 2, G_TRI = 3, G_BVH = 4, G_OBJ = 5 };      // G_OBJ: BVH leaves only — a run of sub-objects (below)
 enum OpKind : uint32_t { OP_TRANSLATE = 0, OP_ROTATE = 1, OP_FLIP = 2 };
 enum MatKind : uint32_t { M_LAMBERTIAN = 0, M_METAL = 1, M_DIELECTRIC = 2, M_DIFFUSE_LIGHT = 3, M_ISOTROPIC = 4, M_PBR = 5 };
 // DMaterial::kind also carries, above the MatKind byte, whether the material's texture graph reads (u, v) at all (only ImageTexture
@@ -43,14 +44,18 @@ enum Feat : uint32_t {
     F_ALL = 0x7F,
     F_NEAR_FIRST = 1u << 7, // not a scene feature: selects the near-first BVH traversal instantiations (RT_NEAR_FIRST_BVH)
     F_PERSIST = 1u << 8,    // not a scene feature: selects the persistent-traversal loop (mesh scenes whose BVH few rays enter)
+    F_NESTED = 1u << 9,     // a BVH leaf that is not a bare primitive / Cube (any other Hittable: a list, a wrapped object, a medium, another BVH), or a
+                            // ConstantMedium under a wrapper: served by the all-features instantiation only (no BASELINE scene has either)
     F_SPEC = 1u << 11           // not a scene feature: lock-step BVH walk with speculative box steps (scenes whose world IS one BVH; RT_SPECULATE_BVH)
 };
 
 static const uint32_t BVH_LEAF = 0x80000000u;     // leaf: node.a = bit 31 | GeomKind << 28 | first index, node.b = count, node.c = rank in DFS
                                                    //       preorder (= the reference's visiting order: resolves exact-t ties in near-first mode);
                                                    // inner: node.a = split axis (0..2), node.b = right child, node.c = left child
-static const int RT_MAX_OPS = 4;                   // wrapper chain length limit
+static const int RT_MAX_OPS = 8;                   // wrapper chain length limit (a sub-object's chain counts the wrappers around its BVHs too)
 static const int RT_MAX_BVH_DEPTH = 48;
+static const int RT_MAX_NEST = 1;                  // BVHs inside BVH leaves: a BVH (level 0) may hold BVHs (level 1), whose own leaves may be any Hittable but another BVH
+                                                   // (the kernel holds one copy of the walk per level: rt_kernel.hip bvh_hit_filt<.., NEST>)
 
 // Records are 16-byte aligned (the BVH node a whole 64 / 32 bytes) so that a per-lane fetch is a few 16-byte loads inside one
 // cache line instead of a string of 8-byte loads straddling two.
@@ -59,7 +64,12 @@ template <typename T> struct alignas(16) DSphere { T c[3], r; uint32_t mat, pad;
 template <typename T> struct alignas(16) DMSphere { T c0[3], c1[3], t0, t1, r; uint32_t mat, pad; };      // src/sphere.rs:122-129
 template <typename T> struct alignas(16) DTri { T v0[3], e1[3], e2[3]; uint32_t mat, pad; };              // src/tri.rs:9-12 (e1 = v1-v0, e2 = v2-v0, as tri.rs:27-28 computes per hit)
 template <typename T> struct alignas(16) DOp { uint32_t kind, axis; T x, y, z; };             // translate: offset; rotate: x = sin, y = cos (src/rotate.rs:23-30)
-struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t is_cube, pad1; };   // is_cube: the 6 rects are ONE Cube's faces in cube.rs:17-24 order (a run of six bare AARects is not)
+struct alignas(16) DObject { uint32_t geom_kind, geom_first, geom_count, first_op, n_ops; int32_t medium; uint32_t is_cube, nest; };   // is_cube: the 6 rects are ONE Cube's faces in cube.rs:17-24 order (a run of six bare AARects is not)
+// nest (F_NESTED kernels; 0 everywhere else) = n_outer | med_at << 8.  A SUB-OBJECT — what a BVH leaf of kind G_OBJ holds: objects[first ..
+// first + count) behind the world's n_objects — carries its WHOLE wrapper chain from the world down (the hit record is rebuilt from the
+// world ray), of which the first n_outer ops lie outside its BVH: the walk's ray has them applied already, a leaf step applies the rest.
+// med_at = the ops that lie outside the object's ConstantMedium (its free-flight length is measured with the ray as the medium receives
+// it, medium.rs:40; 0 when the medium is the outermost wrapper, the only form the other kernels serve).
 template <typename T> struct alignas(16) DBvhNode { T mn[3], mx[3]; uint32_t a, b, c, skip; };      // f64: 64 B = four 16-byte pieces of one line; f32: 48 B
 // Conservative f32 companion of a BVH node (same id, same skip link), what the f64 kernels' box steps read (rt_kernel.hip: "filtered walk"):
 // b = {min.x, max.x, min.y, max.y, min.z, max.z} rounded OUTWARD to f32; info = left child id (inner) or own id | FNODE_LEAF (leaf).

@@ -602,14 +602,32 @@ template <typename T> DEV uint32_t exact_step(const KParams<T>& P, uint32_t st, 
     if (!box_inside_exact(nd, o, inv, t_min, closest)) return state_of(P, nd.skip);
     return (nd.a & BVH_LEAF) ? (id | FNODE_LEAF) : state_of(P, nd.c);
 }
+// BVH leaves that are not bare primitives (F_NESTED kernels): any Hittable is a legal child of BVH::new (bvh.rs:18-31 needs only its
+// bounding_box) — a list, a wrapped object, a ConstantMedium, another BVH.  Such a leaf holds a run of SUB-OBJECTS (rt_ir.h: DObject::nest)
+// and its leaf step is HittableList::hit (hit.rs:59-71) over them through the same object_hit the world list uses, one nesting level down.
+struct HitId { uint32_t obj, prim; };   // prim: GeomKind << 28 | index, or PRIM_MEDIUM; obj: the object (top-level, or the sub-object of a G_OBJ leaf)
+static const uint32_t PRIM_MEDIUM = 0xFFFFFFFFu, NO_SUB = 0xFFFFFFFFu;
+template <uint32_t FEATS> struct Nested { static constexpr bool on = (FEATS & F_NESTED) != 0u; };
+template <typename T, uint32_t FEATS, int NEST>
+DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack);
+template <typename T, uint32_t FEATS, int NEST>
+DEV bool subobjects_hit(const KParams<T>& P, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, Rng& rng, T& t_out, uint32_t& prim_out, uint32_t& sub_out) {
+    T closest = t_max; bool any = false;
+    HitId id; id.obj = 0u; id.prim = 0u;
+    if constexpr (Nested<FEATS>::on && NEST <= RT_MAX_NEST) {
+        for (uint32_t i = first; i < first + count; i++) object_hit<T, FEATS, NEST + 1>(P, i, ld_obj(P.objects + i), ray, t_min, rng, closest, id, any, nullptr);
+    }
+    t_out = closest; prim_out = id.prim; sub_out = id.obj;
+    return any;
+}
 // which instantiations walk this way (the host sizes the LDS node cache by the same rule: rt_launch.h filtered_walk)
 template <typename T, uint32_t FEATS> struct Filt { static constexpr bool on = (FEATS & F_BVH) != 0u && (FEATS & F_NEAR_FIRST) == 0u; };
 
 // Box steps and leaf steps are chosen by vote as in bvh_hit_ww.  SPEC (worlds that are one BVH: every lane walks): a lane does not wait
 // with one pending leaf, it walks on with its closest hit as it is and waits with two — every leaf is tested against its own box with
 // the closest hit of THAT moment in the leaf step anyway, so walking ahead with a stale (larger) bound only visits more.
-template <typename T, uint32_t FEATS, bool SPEC>
-DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+template <typename T, uint32_t FEATS, bool SPEC, int NEST>
+DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, Rng& rng, uint32_t& sub_out) {
     const V3<T> inv = mk<T>(T(1.0) / ray.d.x, T(1.0) / ray.d.y, T(1.0) / ray.d.z);
     T closest = t_max;
     bool any = false;
@@ -642,6 +660,16 @@ DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
         if (leaf != ST_DONE) {
             const DBvhNode<T> lf = ld_node_at(P.bvh, leaf);
             T t; uint32_t prim;
+            if constexpr (Nested<FEATS>::on) {
+                // (untamed waves — a Rotate child's box is all of space, rotate.rs:40-57 — come here from exact_step, which has run AABB::hit on the leaf's own box)
+                uint32_t sub = NO_SUB;
+                if (!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) {                     // aabb.rs:19-36 on the leaf's own box
+                    const uint32_t lk = (lf.a >> 28) & 7u;
+                    const bool hit = lk == G_OBJ ? subobjects_hit<T, FEATS, NEST>(P, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, rng, t, prim, sub)
+                                                 : range_hit<T, FEATS>(P, lk, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u);
+                    if (hit) { closest = t; prim_out = prim; sub_out = lk == G_OBJ ? sub : NO_SUB; any = true; F.c = up32(closest); }
+                }
+            } else
             if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
                 range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
             if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
@@ -716,9 +744,9 @@ DEV bool bvh_hit_ww(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_
     return any;
 }
 
-template <typename T, uint32_t FEATS>
-DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack) {
-    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<T, FEATS, (FEATS & F_SPEC) != 0u>(P, root, ray, t_min, t_max, t_out, prim_out);
+template <typename T, uint32_t FEATS, int NEST>
+DEV bool bvh_hit(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, uint32_t* stack, Rng& rng, uint32_t& sub_out) {
+    if constexpr (Filt<T, FEATS>::on) return bvh_hit_filt<T, FEATS, (FEATS & F_SPEC) != 0u, NEST>(P, root, ray, t_min, t_max, t_out, prim_out, rng, sub_out);
     return bvh_hit_ww<T, FEATS>(P, root, ray, t_min, t_max, t_out, prim_out, stack);
 }
 
@@ -741,19 +769,56 @@ template <typename T> DEV void op_fwd(const DOp<T>& op, RayT<T>& r) {
 }
 
 // ------------------------------------------------------------------ world.hit: closest hit over the top-level list
-struct HitId { uint32_t obj, prim; };   // prim: GeomKind << 28 | index, or PRIM_MEDIUM
-static const uint32_t PRIM_MEDIUM = 0xFFFFFFFFu;
-
-template <typename T, uint32_t FEATS>
-DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack) {
-    if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) return bvh_hit<T, FEATS>(P, ob.geom_first, r, t_min, t_max, t, prim, stack);
+// (sub: the sub-object a hit inside a BVH belongs to when the leaf was a G_OBJ one — F_NESTED kernels; NO_SUB otherwise)
+template <typename T, uint32_t FEATS, int NEST = 0>
+DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack, Rng& rng, uint32_t& sub) {
+    if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) {
+        if constexpr (NEST <= RT_MAX_NEST) return bvh_hit<T, FEATS, NEST>(P, ob.geom_first, r, t_min, t_max, t, prim, stack, rng, sub);
+        else return false;              // (the flattener refuses BVHs nested deeper)
+    }
     return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube != 0u);
+}
+// One object under HittableList::hit in an F_NESTED kernel — a top-level object (NEST 0) or a sub-object of a BVH leaf (NEST >= 1; `ray` is
+// then the ray as the enclosing BVH received it: the first n_outer ops of the object's chain are already in it).  Same arithmetic as
+// object_hit's general form; additionally a ConstantMedium may stand anywhere in the chain (medium.rs:27-61 measures the free flight with
+// the ray IT receives: the ops outside it applied, those between it and its boundary not) and a hit inside a BVH names its sub-object.
+template <typename T, uint32_t FEATS, int NEST>
+DEV void object_hit_nested(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any) {
+    const uint32_t n_outer = ob.nest & 0xFFu, med_at = (ob.nest >> 8) & 0xFFu;
+    RayT<T> r = ray;
+    uint32_t sub = NO_SUB;
+    if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
+        for (uint32_t k = n_outer; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
+        T t; uint32_t prim;
+        if (geom_hit<T, FEATS, NEST>(P, ob, r, t_min, closest, t, prim, nullptr, rng, sub)) { closest = t; id.obj = sub != NO_SUB ? sub : oi; id.prim = prim; any = true; }
+        return;
+    }
+    for (uint32_t k = n_outer; k < med_at; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);        // the ray ConstantMedium::hit receives
+    const T len = length(r.d);                                                                     // medium.rs:40
+    for (uint32_t k = med_at; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);        // ... and its boundary
+    T t1, t2; uint32_t p1, p2;
+    if (geom_hit<T, FEATS, NEST>(P, ob, r, -Lim<T>::max(), Lim<T>::max(), t1, p1, nullptr, rng, sub)) {          // medium.rs:29
+        if (geom_hit<T, FEATS, NEST>(P, ob, r, t1 + T(0.0001), Lim<T>::max(), t2, p2, nullptr, rng, sub)) {      // medium.rs:30
+            if (t1 < t_min) t1 = t_min;
+            if (t2 > closest) t2 = closest;
+            if (t1 < t2) {
+                T distance_inside_boundary = (t2 - t1) * len;
+                T hit_distance = cl(&P.media[ob.medium].neg_inv_density) * m_log(rng_u01(rng, T(0)));
+                if (hit_distance < distance_inside_boundary) {
+                    closest = t1 + hit_distance / len;
+                    id.obj = oi; id.prim = PRIM_MEDIUM; any = true;
+                }
+            }
+        }
+    }
 }
 
 // One object of the top-level list under HittableList::hit (hit.rs:59-71): offered [t_min, closest], a hit replaces the
 // running (closest, id).  ConstantMedium objects draw from the path's RNG (medium.rs:44).
-template <typename T, uint32_t FEATS>
+template <typename T, uint32_t FEATS, int NEST = 0>
 DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const RayT<T>& ray, T t_min, Rng& rng, T& closest, HitId& id, bool& any, uint32_t* stack) {
+    if constexpr (Nested<FEATS>::on) { object_hit_nested<T, FEATS, NEST>(P, oi, ob, ray, t_min, rng, closest, id, any); return; }
+    uint32_t no_sub = NO_SUB;          // (only F_NESTED kernels have sub-objects)
     if (FEATS == 0u && ob.n_ops == 2u) {        // Translate(RotateY(..)), the reference's instance idiom (main.rs:300-309): straight-line code
         const DOp<T> o0 = ld_op(P.ops + ob.first_op), o1 = ld_op(P.ops + ob.first_op + 1u);
         if (o0.kind == OP_TRANSLATE && o1.kind == OP_ROTATE && o1.axis == 1u) {
@@ -763,25 +828,25 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
             r.d.x = o1.y * ray.d.x - o1.x * ray.d.z; r.d.y = ray.d.y; r.d.z = o1.x * ray.d.x + o1.y * ray.d.z;
             r.tm = ray.tm;
             T t; uint32_t prim;
-            if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+            if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
             return;
         }
     }
     if (FEATS == 0u && ob.n_ops == 0u) {        // no wrapper: test the path's own ray (no copy of it into the registers the wrappers rewrite)
         T t; uint32_t prim;
-        if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
         return;
     }
     RayT<T> r = ray;
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
         T t; uint32_t prim;
-        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     } else {
         // ConstantMedium::hit, medium.rs:27-61
         T t1, t2; uint32_t p1, p2;
-        if (geom_hit<T, FEATS>(P, ob, r, -Lim<T>::max(), Lim<T>::max(), t1, p1, stack)) {
-            if (geom_hit<T, FEATS>(P, ob, r, t1 + T(0.0001), Lim<T>::max(), t2, p2, stack)) {
+        if (geom_hit<T, FEATS>(P, ob, r, -Lim<T>::max(), Lim<T>::max(), t1, p1, stack, rng, no_sub)) {
+            if (geom_hit<T, FEATS>(P, ob, r, t1 + T(0.0001), Lim<T>::max(), t2, p2, stack, rng, no_sub)) {
                 if (t1 < t_min) t1 = t_min;
                 if (t2 > closest) t2 = closest;
                 if (t1 < t2) {
@@ -855,6 +920,30 @@ DEV void finalize_hit(const KParams<T>& P, const RayT<T>& ray, T t, HitId id, bo
     const DObject ob = ld_obj(P.objects + id.obj);
     rec.t = t; rec.u = T(0); rec.v = T(0);
     if ((FEATS & F_MEDIUM) && id.prim == PRIM_MEDIUM) {                               // medium.rs:45-55
+        if constexpr (Nested<FEATS>::on) {
+            // the medium may stand under wrappers (med_at of the chain's ops): its record is made with the ray it received and then goes
+            // back up through them like any other record (translate.rs:24-28, rotate.rs:88-104, hit.rs:113-119)
+            const uint32_t med_at = (ob.nest >> 8) & 0xFFu;
+            RayT<T> rm = ray;
+            for (uint32_t k = 0; k < med_at; k++) op_fwd(ld_op(P.ops + ob.first_op + k), rm);
+            rec.p = ray_at(rm, t);
+            rec.n = mk<T>(T(1.0), T(0), T(0));
+            rec.front = false;
+            rec.mat = cl(&P.media[ob.medium].mat);
+            for (int k = (int)med_at - 1; k >= 0; k--) {
+                const DOp<T> op = ld_op(P.ops + ob.first_op + (uint32_t)k);
+                if (op.kind == OP_TRANSLATE) rec.p = rec.p + mk<T>(op.x, op.y, op.z);
+                else if (op.kind == OP_ROTATE) {
+                    RayT<T> rr = ray;                                                     // the ray this Rotate handed to its child
+                    for (int q = 0; q <= k; q++) op_fwd(ld_op(P.ops + ob.first_op + (uint32_t)q), rr);
+                    rot_back(op.axis, op.x, op.y, rec.p);
+                    V3<T> nw = rec.n;
+                    rot_back(op.axis, op.x, op.y, nw);
+                    set_face_normal(rec, rr.d, nw);
+                } else rec.front = !rec.front;
+            }
+            return;
+        }
         rec.p = ray_at(ray, t);
         rec.n = mk<T>(T(1.0), T(0), T(0));
         rec.front = false;
@@ -2043,6 +2132,7 @@ template <typename T, typename F, typename L> static auto dispatch(uint32_t scen
     const bool nf = (flags & 8u) && (scene_feats & F_BVH);          // RT_NEAR_FIRST_BVH
     const bool ps = (flags & 16u) && (scene_feats & F_BVH);         // RT_PERSISTENT_BVH
     if ((scene_feats & ~FEATS_LEAN) == 0u) return lean();
+    if (scene_feats & F_NESTED) return f(std::integral_constant<uint32_t, F_ALL | F_NESTED>());      // any Hittable as a BVH leaf: one instantiation (reference order, lock-step)
     if ((scene_feats & ~FEATS_MESH) == 0u) {
         if (ps) return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH | F_PERSIST>());
         return nf ? f(std::integral_constant<uint32_t, FEATS_MESH | F_NEAR_FIRST>()) : f(std::integral_constant<uint32_t, FEATS_MESH>());

@@ -234,3 +234,140 @@ def test_random_list_scene_parity(pbe, obe, seed):
     bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, rs_, 0.0)))).any(axis=-1)
     assert bad.sum() <= 2, f"seed {seed}: {int(bad.sum())} of {W * H * spp} samples diverged; first at {np.argwhere(bad)[:3].tolist()}"
     assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+
+
+def _rand_nested_scene(be, seed, kinds=None):
+    """BVHs whose children are ANY Hittable (BVH::new takes Vec<Box<dyn Hittable>> and needs only bounding_box, bvh.rs:18-31): bare
+    primitives beside wrapped ones (Translate / Rotate — whose box is all of space, quirk B3, so the wave walks the exact f64 nodes —
+    / FlipNormal, chains of them), HittableLists (of primitives, of wrapped objects, wrapped themselves), ConstantMedia (around a sphere,
+    a wrapped cube; under wrappers of their own), nested BVHs (of primitives and of wrapped objects), the whole BVH under 0-2 wrappers;
+    and at the top level a ConstantMedium under wrappers.  `kinds`: restrict the children to these kinds (the per-kind tests)."""
+    rs = np.random.RandomState(5000 + seed)
+    b = SceneBuilder(be)
+
+    def col(lo=0.05, hi=0.95):
+        return tuple(float(x) for x in rs.uniform(lo, hi, 3))
+
+    def material():
+        k = rs.randint(0, 6)
+        if k <= 2:
+            return b.Lambertian(b.ConstantTexture(col()))
+        if k == 3:
+            return b.Metal(col(0.4, 1.0), float(rs.choice([0.0, 0.3])))
+        if k == 4:
+            return b.Dielectric(1.5)
+        return b.Lambertian(b.CheckTexture(b.ConstantTexture(col()), b.ConstantTexture(col())))
+
+    def pos(s=60.0):
+        return tuple(float(x) for x in rs.uniform(-s, s, 3))
+
+    def prim(s=60.0):
+        k = rs.randint(0, 5)
+        m = material()
+        p = np.array(pos(s))
+        if k == 0:
+            return b.Sphere(tuple(p), float(rs.uniform(3, 10)), m)
+        if k == 1:
+            return b.MovingSphere(tuple(p), tuple(p + rs.uniform(-3, 3, 3)), 0.0, 1.0, float(rs.uniform(3, 8)), m)
+        if k == 2:
+            return b.Cube(tuple(p), tuple(p + rs.uniform(5, 18, 3)), m)
+        if k == 3:
+            return b.Triangle([tuple(p), tuple(p + rs.uniform(-20, 20, 3)), tuple(p + rs.uniform(-20, 20, 3))], m)
+        return b.AARect(Plane.XY, float(p[0]), float(p[0] + 14), float(p[1]), float(p[1] + 14), float(p[2]), m)
+
+    def wrap(h, n=None, no_rotate=False):
+        for _ in range(rs.randint(1, 3) if n is None else n):
+            k = rs.randint(0, 2 if no_rotate else 3)
+            if k == 0:
+                h = b.Translate(h, pos(25.0))
+            elif k == 1:
+                h = b.FlipNormal(h)
+            else:
+                h = b.Rotate(int(rs.randint(0, 3)), h, float(rs.uniform(-60, 60)))
+        return h
+
+    def medium(s=50.0):
+        if rs.rand() < 0.5:
+            bd = b.Sphere(pos(s), float(rs.uniform(8, 20)), b.Dielectric(1.5))
+        else:
+            mn = np.array(pos(s * 0.6))
+            bd = wrap(b.Cube(tuple(mn), tuple(mn + rs.uniform(10, 25, 3)), b.Lambertian(b.ConstantTexture(col()))), int(rs.randint(0, 3)))
+        return b.ConstantMedium(bd, float(rs.choice([0.01, 0.05, 0.2])), b.ConstantTexture(col()))
+
+    def child(kind):
+        if kind == "prim":
+            return prim()
+        if kind == "translate":
+            return b.Translate(prim(40.0), pos(25.0))
+        if kind == "flip":
+            return b.FlipNormal(prim())
+        if kind == "rotate":
+            return b.Rotate(int(rs.randint(0, 3)), prim(40.0), float(rs.uniform(-60, 60)))
+        if kind == "chain":
+            return wrap(prim(40.0), int(rs.randint(2, 4)))
+        if kind == "list":
+            l = b.HittableList()
+            for _ in range(rs.randint(1, 4)):
+                l.push(prim() if rs.rand() < 0.6 else wrap(prim(40.0), 1, no_rotate=True))
+            return l if rs.rand() < 0.6 else wrap(l, 1, no_rotate=True)
+        if kind == "medium":
+            return medium() if rs.rand() < 0.6 else wrap(medium(35.0), 1, no_rotate=True)
+        if kind == "bvh":
+            inner = [prim() if rs.rand() < 0.7 else wrap(prim(40.0), 1, no_rotate=True) for _ in range(rs.randint(1, 7))]
+            h = b.BVH(inner, 0.0, 1.0)
+            return h if rs.rand() < 0.6 else wrap(h, 1, no_rotate=True)
+        raise KeyError(kind)
+
+    all_kinds = ["prim", "translate", "flip", "rotate", "chain", "list", "medium", "bvh"]
+    world = b.HittableList()
+    glow = b.DiffuseLight(b.ConstantTexture(col(3.0, 9.0)))
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, -30.0, 30.0, -30.0, 30.0, 80.0, glow))
+    world.push(lamp)
+    world.push(b.AARect(Plane.XZ, -300.0, 300.0, -300.0, 300.0, -70.0, b.Lambertian(b.ConstantTexture(col()))))
+    for _ in range(rs.randint(0, 3)):
+        world.push(prim())
+    n_children = rs.randint(3, 14)
+    pool = kinds if kinds is not None else all_kinds
+    children = [child(pool[rs.randint(0, len(pool))]) if rs.rand() < 0.7 else prim() for _ in range(n_children)]
+    bvh = b.BVH(children, 0.0, 1.0)
+    world.push(wrap(bvh, int(rs.randint(0, 3)), no_rotate=rs.rand() < 0.7))
+    if kinds is None or "medium" in kinds:
+        if rs.rand() < 0.5:
+            world.push(wrap(medium(40.0), int(rs.randint(1, 3))))          # a ConstantMedium under wrappers at the top level
+    b.set_scene(world, [lamp] if rs.rand() < 0.7 else [])
+    cam = Camera((float(rs.uniform(-30, 30)), float(rs.uniform(10, 60)), -190.0), (0.0, 5.0, 0.0), (0.0, 1.0, 0.0), 45.0, 1.0,
+                 float(rs.choice([0.0, 1.0])), 190.0, 0.0, 1.0)
+    return b, cam, col(0.1, 0.6)
+
+
+def _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, seed, W=40, H=40, spp=8, depth=12, max_bad=2):
+    from oracle import orc
+    ref, rs_, cnt = orc.render(ob, ocam, obg, W, H, spp, depth, seed=seed, want_samples=True, want_counters=True)
+    got, gs = R.render(pb, pcam, pbg, W, H, spp, depth, seed=seed, want_samples=True)
+    assert np.array_equal(np.isnan(gs), np.isnan(rs_)), "NaN pattern differs"
+    assert np.array_equal(np.isinf(gs), np.isinf(rs_))
+    fin = np.isfinite(rs_)
+    d = np.abs(np.where(fin, gs, 0.0) - np.where(fin, rs_, 0.0))
+    bad = (d > SAMPLE_RTOL * (1.0 + np.abs(np.where(fin, rs_, 0.0)))).any(axis=-1)
+    assert bad.sum() <= max_bad, f"{int(bad.sum())} of {W * H * spp} samples diverged; first at {np.argwhere(bad)[:3].tolist()}"
+    assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+    return cnt
+
+
+@pytest.mark.parametrize("kind", ["translate", "flip", "rotate", "chain", "list", "medium", "bvh"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_bvh_children_of_every_hittable_kind(pbe, obe, kind, seed):
+    """One kind of non-primitive BVH child at a time (beside bare primitives), against the oracle per sample: BVH::new accepts any
+    Hittable (bvh.rs:18-31); until round 6 rt_bvh refused everything but Sphere / MovingSphere / AARect / Cube / Triangle."""
+    ob, ocam, obg = _rand_nested_scene(obe, 100 * seed + 7, [kind])
+    pb, pcam, pbg = _rand_nested_scene(pbe, 100 * seed + 7, [kind])
+    _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, 11 + seed)
+    li = R.last_loop_info(pb)
+    assert li["feats"] == 639 and li["shape"] == "lock-step", li        # F_ALL | F_NESTED: the one instantiation with object leaves
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_random_nested_scene_parity(pbe, obe, seed):
+    ob, ocam, obg = _rand_nested_scene(obe, seed)
+    pb, pcam, pbg = _rand_nested_scene(pbe, seed)
+    _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, 53 + seed)

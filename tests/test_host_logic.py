@@ -153,18 +153,28 @@ def test_error_paths_return_errors(pbe):
         b.BVH([], 0.0, 1.0)
     assert pbe.lib.rt_sphere(b.h, (C.c_double * 3)(0, 0, 0), 1.0, 99) < 0
     assert b"bad material" in pbe.lib.rt_last_error()
-    # a BVH child without a device leaf form
+    # a BVH child without a bounding box (bvh.rs:28,61 panic "no bounding box in bvh node"): an empty list, or a wrapper of one
     s = b.Sphere((0, 0, 0), 1.0, m)
-    world = b.BVH([b.Translate(s, (1, 0, 0))], 0.0, 1.0)
+    world = b.BVH([s, b.Translate(b.HittableList(), (1, 0, 0))], 0.0, 1.0)
     b.set_scene(world, [])
-    with pytest.raises(R.RenderError, match="unsupported BVH child"):
+    with pytest.raises(R.RenderError, match="no bounding box in bvh node"):
         R.flatten(b)
-    # ConstantMedium must be the outermost wrapper
+    # BVHs inside BVH leaves: one level (rt_ir.h RT_MAX_NEST); deeper is refused, not mis-rendered
     b2 = SceneBuilder(pbe)
-    s2 = b2.Sphere((0, 0, 0), 1.0, b2.Dielectric(1.5))
-    b2.set_scene(b2.Translate(b2.ConstantMedium(s2, 0.1, b2.ConstantTexture((1, 1, 1))), (1, 0, 0)), [])
-    with pytest.raises(R.RenderError, match="outermost"):
+    m2 = b2.Lambertian(b2.ConstantTexture((1, 1, 1)))
+    lvl2 = b2.BVH([b2.Sphere((0, 0, 0), 1.0, m2), b2.Sphere((3, 0, 0), 1.0, m2)], 0.0, 1.0)
+    lvl1 = b2.BVH([lvl2, b2.Sphere((6, 0, 0), 1.0, m2)], 0.0, 1.0)
+    b2.set_scene(b2.BVH([lvl1, b2.Sphere((9, 0, 0), 1.0, m2)], 0.0, 1.0), [])
+    with pytest.raises(R.RenderError, match="RT_MAX_NEST"):
         R.flatten(b2)
+    b2.set_scene(lvl1, [])
+    assert R.flatten(b2)["bvh_nodes"] == 3 + 3
+    # a ConstantMedium inside a ConstantMedium's boundary stays refused
+    b4 = SceneBuilder(pbe)
+    inner = b4.ConstantMedium(b4.Sphere((0, 0, 0), 1.0, b4.Dielectric(1.5)), 0.1, b4.ConstantTexture((1, 1, 1)))
+    b4.set_scene(b4.ConstantMedium(b4.Translate(inner, (1, 0, 0)), 0.1, b4.ConstantTexture((1, 1, 1))), [])
+    with pytest.raises(R.RenderError, match="nested ConstantMedium"):
+        R.flatten(b4)
     b3 = SceneBuilder(pbe)
     with pytest.raises(R.RenderError, match="world not set"):
         R.flatten(b3)
@@ -247,6 +257,68 @@ def test_jpeg_restart_intervals(tmp_path):
     ours = np.frombuffer(data, dtype=np.uint8).reshape(h, w, 3).astype(int)
     ref = np.asarray(Image.open(p).convert("RGB")).astype(int)
     assert np.abs(ours - ref).max() <= 3
+
+
+def _bvh_with_children(be, kind):
+    """A BVH of four bare primitives and three children of `kind` (tests of rt_bvh over every Hittable, bvh.rs:18-31); returns
+    (builder, the BVH's handle)."""
+    b = SceneBuilder(be)
+    m = b.Lambertian(b.ConstantTexture((0.5, 0.5, 0.5)))
+    glass = b.Dielectric(1.5)
+    prims = [b.Sphere((0.0, 0.0, 0.0), 1.0, m), b.Cube((3.0, -1.0, -1.0), (5.0, 1.5, 1.0), m), b.Triangle([(7.0, 0.0, 0.0), (9.0, 0.5, 0.0), (8.0, 2.0, 1.0)], m),
+             b.MovingSphere((-4.0, 0.0, 0.0), (-4.0, 0.5, 0.0), 0.0, 1.0, 0.8, m)]
+
+    def one(i):
+        base = b.Sphere((2.0 * i, 4.0, 1.0), 0.7, m) if i % 2 == 0 else b.Cube((2.0 * i, 3.0, 0.0), (2.0 * i + 1.0, 4.5, 1.5), m)
+        if kind == "translate": return b.Translate(base, (0.5, -0.25, 2.0))
+        if kind == "flip": return b.FlipNormal(base)
+        if kind == "rotate": return b.Rotate(i % 3, base, 20.0 + 10.0 * i)
+        if kind == "rotate_translate": return b.Translate(b.Rotate(1, base, 15.0), (1.0, 0.0, -1.0))
+        if kind == "list":
+            l = b.HittableList(); l.push(base); l.push(b.Translate(b.Sphere((2.0 * i, 6.0, 0.0), 0.5, m), (0.0, 0.0, 1.0))); l.push(b.AARect(0, 0.0, 1.0, 0.0, 1.0, 5.0 + i, m))
+            return l
+        if kind == "medium": return b.ConstantMedium(b.Translate(b.Sphere((2.0 * i, 4.0, 1.0), 0.9, glass), (0.0, 1.0, 0.0)), 0.5, b.ConstantTexture((1.0, 1.0, 1.0)))
+        if kind == "bvh": return b.BVH([base, b.Sphere((2.0 * i + 0.5, 6.0, 0.0), 0.4, m), b.FlipNormal(b.Sphere((2.0 * i - 0.5, 7.0, 0.5), 0.3, m))], 0.0, 1.0)
+        raise KeyError(kind)
+
+    h = b.BVH(prims + [one(i) for i in range(3)], 0.0, 1.0)
+    return b, h
+
+
+@pytest.mark.parametrize("kind", ["translate", "flip", "rotate", "rotate_translate", "list", "medium", "bvh"])
+def test_bvh_accepts_every_hittable_kind(kind, pbe, obe):
+    """BVH::new takes Vec<Box<dyn Hittable>> and needs only bounding_box (bvh.rs:18-31,52-63): HittableList (hit.rs:73-88), FlipNormal
+    (hit.rs:122-124), Translate (translate.rs:32-40), Rotate (rotate.rs:37-66,108-110: the whole-space box of quirk B3), ConstantMedium
+    (medium.rs:63-65) and BVH itself (bvh.rs:93-95) all provide one.  Host side of it (the samples: tests/test_fuzz_gpu.py): such a child
+    becomes a leaf of kind G_OBJ over the sub-objects it flattens to, the tree is the reference's (root box equal to the oracle's
+    bounding_box of the same BVH, bit for bit), and the skip links thread all of it."""
+    b, h = _bvh_with_children(pbe, kind)
+    ob, oh = _bvh_with_children(obe, kind)
+    world = b.HittableList(); world.push(b.Translate(h, (0.0, 0.0, 3.0))); world.push(b.AARect(1, -50.0, 50.0, -50.0, 50.0, -5.0, b.Lambertian(b.ConstantTexture((0.2, 0.2, 0.2)))))
+    b.set_scene(world, [])
+    c = R.flatten(b)
+    n = c["bvh_nodes"]
+    assert n == 2 * 7 - 1 + (3 * (2 * 3 - 1) if kind == "bvh" else 0)
+    links = (C.c_uint32 * (4 * n))(); roots = (C.c_uint32 * 8)(); n_roots = C.c_uint32(0)
+    assert pbe.lib.rt_debug_bvh_links(b.h, links, n, roots, 8, C.byref(n_roots)) == n
+    L = np.frombuffer(links, np.uint32).reshape(n, 4)
+    LEAF = 1 << 31
+    leaf_kinds = ((L[:, 0] >> 28) & 7)[(L[:, 0] & LEAF) != 0]
+    assert (leaf_kinds == 5).sum() == (3 + 3 if kind == "bvh" else 3)          # G_OBJ: the three children (and, nested, one FlipNormal(Sphere) in each inner BVH)
+    assert n_roots.value == (4 if kind == "bvh" else 1)
+    # 2 top-level objects; the sub-objects behind them: one per child (a list: its three items)
+    assert c["objects"] == 2 + {"list": 9, "bvh": 3 + 3}.get(kind, 3)
+    eb = np.zeros((n, 6)); fm = C.c_float(0)
+    pbe.lib.rt_debug_filter_nodes.restype = C.c_int
+    pbe.lib.rt_debug_filter_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+    assert pbe.lib.rt_debug_filter_nodes(b.h, None, None, eb.ctypes.data, n, C.byref(fm)) == n
+    box = np.zeros(6)
+    assert obe.lib.orc_bounding_box(ob.h, oh.id, 0.0, 1.0, box.ctypes.data_as(C.POINTER(C.c_double))) == 1
+    assert np.array_equal(eb[roots[0]].view(np.uint64), box.view(np.uint64)), (eb[roots[0]], box)
+    if kind in ("rotate", "rotate_translate"):
+        assert np.abs(box).max() > 1e308 and fm.value == 0.0                   # quirk B3: all of space; no f32 filter over such a tree (the exact walk)
+    else:
+        assert fm.value >= 1.0
 
 
 @pytest.mark.parametrize("name", ["random", "final", "teapot"])
