@@ -259,6 +259,13 @@ int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 /* Diagnostic builds (-DRT_DIAG) only (zeros in a normal build): [0..5] wave-cycle sums of the six kernel sections, [6] rect tests
  * counted per wavefront, [7] those among them in which no lane's plane distance lay in [t_min, closest] (-DRT_DIAG_RECTS builds). */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
+/* Test aid (host only, no GPU): the flattened object table, out[8 i ..] = {geometry kind (0 rect, 1 sphere, 2 moving sphere, 3 triangle,
+ * 4 BVH root), first primitive / root node, count, first wrapper op, number of wrapper ops, medium index (0xFFFFFFFF: none), is_cube
+ * (1: the six rects are one Cube's faces; 2: a run of rects with parallel pairs — bit j of the next word: rects j and j + 1 have the same
+ * plane and bounds and are tested as a pair, rt_kernel.hip rect_pair), nest}: the world's top-level objects (HittableList push order,
+ * runs of bare primitives merged) first — *n_top_out of them — then the sub-objects BVH leaves of other Hittable kinds refer to.
+ * Returns the number of objects or -1. */
+int rt_debug_objects(rt_scene*, uint32_t* out, uint32_t max_objects, uint32_t* n_top_out);
 /* Test aid (host only, no GPU): the flattened BVH's link words, out[4*i..] = node i's {a, b, c, skip}: `a` bit 31 marks a leaf (then kind
  * and first primitive; b = count, c = the leaf's rank in the reference's depth-first order), otherwise a = split axis, b = right child,
  * c = left child; skip = the node BVH::hit's recursion (src/bvh.rs:77-91) reaches next once this node's subtree is finished or culled

@@ -258,14 +258,17 @@ struct Flattener {
             uint32_t kind, first, count;
             if (!simple_geom(items[0], kind, first, count)) {
                 // any other Hittable: the sub-objects it flattens to (a list may give several: HittableList::hit over them, hit.rs:59-71)
+                // (collected apart and appended as one run: a nested BVH among them puts ITS leaves' sub-objects into `subs` on the way)
                 std::vector<DObject>* const saved = target;
-                target = &subs;
-                const size_t s0 = subs.size();
+                std::vector<DObject> mine;
+                target = &mine;
                 Chain c2 = chain; c2.n_outer = chain.n; c2.med_at = -1;
                 const bool ok = emit(items[0], c2, -1, nest + 1);
                 target = saved;
                 if (!ok) return false;
-                kind = G_OBJ; first = (uint32_t)s0; count = (uint32_t)(subs.size() - s0);
+                const size_t s0 = subs.size();
+                subs.insert(subs.end(), mine.begin(), mine.end());
+                kind = G_OBJ; first = (uint32_t)s0; count = (uint32_t)mine.size();
                 f.feats |= F_NESTED;
                 // (count == 0 cannot be reached: a child without sub-objects is an empty list, which has no bounding box)
             }
@@ -555,6 +558,23 @@ bool flatten_scene(Scene& s) {
         for (const HNode& h : s.nodes) if (h.kind == HNode::CUBE) for (int k = 0; k < 3; k++) ok = ok && h.v[k] <= h.v[3 + k];
         s.flat.rect_m = ok ? m : 0.0f;
     }
+    // Parallel pairs among the rects of a top-level run (rt_kernel.hip: rect_pair): consecutive rects with the same plane and the same
+    // bounds, both finite — the left / right walls and the floor / ceiling of the Cornell room.  Bit j of the mask: rects j and j + 1 of
+    // the run are tested as a pair.  (Not in scenes with sub-objects: DObject::nest means something else there.)
+    if (!(s.flat.feats & F_NESTED))
+        for (uint32_t oi = 0; oi < s.flat.n_top; oi++) {
+            DObject& ob = s.flat.objects[oi];
+            if (ob.geom_kind != G_RECT || ob.is_cube != 0u || ob.geom_count < 2u) continue;
+            uint32_t mask = 0u;
+            for (uint32_t j = 0; j + 1u < ob.geom_count && j < 31u; j++) {
+                const DRect<double>& a = s.flat.rects[ob.geom_first + j];
+                const DRect<double>& b = s.flat.rects[ob.geom_first + j + 1u];
+                bool fin = true;
+                for (double v : {a.a0, a.a1, a.b0, a.b1, a.k, b.k}) fin = fin && std::isfinite(v);
+                if (fin && a.plane == b.plane && a.a0 == b.a0 && a.a1 == b.a1 && a.b0 == b.b0 && a.b1 == b.b1) { mask |= 1u << j; j++; }
+            }
+            if (mask) { ob.is_cube = 2u; ob.nest = mask; }
+        }
     s.flat_valid = true;
     return true;
 }

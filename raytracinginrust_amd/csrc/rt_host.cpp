@@ -340,6 +340,22 @@ int rt_scene_flatten(rt_scene* sc, uint32_t counts[12]) {
     return 0;
 }
 
+// Test aid (host only): the flattened object table, out[8*i ..] = object i's {geom_kind, geom_first, geom_count, first_op, n_ops, medium,
+// is_cube, nest} (rt_ir.h DObject): the world's top-level objects first, then the sub-objects of G_OBJ leaves.  Returns the number of
+// objects (all of them), *n_top_out the number of top-level ones; -1 on error.
+int rt_debug_objects(rt_scene* sc, uint32_t* out, uint32_t max_objects, uint32_t* n_top_out) {
+    if (!sc) return set_err("null argument");
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    const HostFlat& f = sc->s.flat;
+    if (n_top_out) *n_top_out = f.n_top;
+    for (size_t i = 0; i < f.objects.size() && i < max_objects && out; i++) {
+        const DObject& o = f.objects[i];
+        const uint32_t w[8] = {o.geom_kind, o.geom_first, o.geom_count, o.first_op, o.n_ops, (uint32_t)o.medium, o.is_cube, o.nest};
+        std::memcpy(out + 8 * i, w, sizeof(w));
+    }
+    return (int)f.objects.size();
+}
+
 // Test aid (host only): the flattened BVH's link words.  out[4*i ..] = node i's {a, b, c, skip} (rt_ir.h DBvhNode); roots_out receives
 // the root node of every BVH object in list order (at most max_roots).  Returns the number of nodes, or -1.
 int rt_debug_bvh_links(rt_scene* sc, uint32_t* out, uint32_t max_nodes, uint32_t* roots_out, uint32_t max_roots, uint32_t* n_roots_out) {

@@ -389,10 +389,46 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
     return true;
 }
 
+// ------------------------------------------------------------------ a parallel pair of AARects: one division instead of two (round 6)
+// Two consecutive rects of a list with the same plane and the same bounds, at k1 and k2 (the Cornell room's left / right walls, its
+// floor / ceiling: main.rs:281-282,285-286).  AARect::hit starts with t = (k - o_k) / d_k and `if t < t_min || t > t_max { return None }`
+// (rect.rs:50-53).  The numerator n = k - o_k is one exact-as-the-reference subtraction; when n and d_k have opposite strict signs, or n
+// is zero and d_k is not (d_k finite), the quotient is negative or a zero of either sign — IEEE division gets the sign right whatever it rounds — and
+// `t < t_min` rejects the rect for every t_min > 0 without the division being made.  So a rect that is BEHIND the ray (n <= 0 < d_k or
+// d_k < 0 <= n) needs no test, and of a parallel pair at most one is not behind whenever the origin lies between the two planes or on
+// one of them — every ray that starts inside the room or on its walls.  When every lane of the wave has (at least) one of the two behind,
+// the wave runs ONE rect test with a per-lane k — the reference's own division, `o + t d` and bounds test (rect.rs:50-60) on the rect
+// that is not behind — and the other rect's outcome is the rejection derived above: per lane the same sequence of (closest, primitive)
+// updates as the two tests in list order, bit for bit.  A lane with both in front (an origin outside the slab), a NaN anywhere (every
+// comparison above is then false) or t_min <= 0 sends the wave through the two plain tests.
+// Which pairs: rt_flatten.cpp marks them per top-level rect run (DObject::is_cube == 2, mask in DObject::nest).
+template <typename T, uint32_t FEATS> struct PairRule { static constexpr bool on = sizeof(T) == 8u && FEATS == 0u; };
+// (d_k finite: -inf / inf would be NaN, which rect.rs:51 does not reject; n may be anything — a NaN n fails both comparisons)
+template <typename T> DEV bool rect_behind(T n, T dk) { return ((n <= T(0) && dk > T(0)) || (n >= T(0) && dk < T(0))) && m_abs(dk) <= Lim<T>::max(); }
+template <typename T>
+DEV bool rect_pair_axes(const DRect<T>& r1, T k2, T ok, T dk, T oa, T da, T ob, T db, T t_min, T& closest, bool& second, bool& hit) {
+    const T n1 = r1.k - ok, n2 = k2 - ok;                              // rect.rs:50, the numerators
+    const bool b1 = rect_behind(n1, dk), b2 = rect_behind(n2, dk);
+    if (__ballot(!(b1 || b2)) != 0ull) return false;                   // some lane has both in front (or a NaN): the two plain tests
+    const T t = (b1 ? n2 : n1) / dk;                                   // rect.rs:50 for the rect that is not behind (both behind: this one is rejected just the same)
+    second = b1; hit = false;
+    if (!(t < t_min || t > closest)) {                                 // rect.rs:51-53
+        const T a = oa + t * da, b = ob + t * db;                      // rect.rs:54-55
+        if (!(a < r1.a0 || a > r1.a1 || b < r1.b0 || b > r1.b1)) { closest = t; hit = true; }     // rect.rs:56-58 (the pair's bounds are equal)
+    }
+    return true;
+}
+template <typename T>
+DEV bool rect_pair(const DRect<T>& r1, T k2, const RayT<T>& ray, T t_min, T& closest, bool& second, bool& hit) {
+    if (r1.plane == 2u) return rect_pair_axes(r1, k2, ray.o.x, ray.d.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, closest, second, hit);
+    if (r1.plane == 1u) return rect_pair_axes(r1, k2, ray.o.y, ray.d.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, closest, second, hit);
+    return rect_pair_axes(r1, k2, ray.o.z, ray.d.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, closest, second, hit);
+}
+
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
-DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false) {
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false, uint32_t pairs = 0u) {
     bool any = false;
     T closest = t_max;
     if constexpr (CubeFast<T, FEATS>::on) {
@@ -409,6 +445,17 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
             __builtin_amdgcn_sched_barrier(0);
             const DRect<T> nxt = ld_rect(P.rects + i + 1);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PairRule<T, FEATS>::on) {
+                if (((pairs >> (i - first)) & 1u) != 0u && t_min > T(0)) {            // wave-uniform: this rect and the next are a parallel pair
+                    bool second, hit;
+                    if (rect_pair(cur, nxt.k, ray, t_min, closest, second, hit)) {
+                        if (hit) { prim_out = (G_RECT << 28) | (i + (second ? 1u : 0u)); any = true; }
+                        i++;                                                          // both records are done
+                        cur = ld_rect(P.rects + i + 1);
+                        continue;
+                    }
+                }
+            }
             T t;
 #ifdef RT_DIAG_RECTS    // (its own build: the two atomics per test distort RT_DIAG's timings) how often a rect test could be skipped for the whole
                         // wave by a filter on t: stats[14] tests, [15] with no lane in range
@@ -776,7 +823,7 @@ DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_
         if constexpr (NEST <= RT_MAX_NEST) return bvh_hit<T, FEATS, NEST>(P, ob.geom_first, r, t_min, t_max, t, prim, stack, rng, sub);
         else return false;              // (the flattener refuses BVHs nested deeper)
     }
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube != 0u);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube == 1u, ob.is_cube == 2u ? ob.nest : 0u);
 }
 // One object under HittableList::hit in an F_NESTED kernel — a top-level object (NEST 0) or a sub-object of a BVH leaf (NEST >= 1; `ray` is
 // then the ray as the enclosing BVH received it: the first n_outer ops of the object's chain are already in it).  Same arithmetic as

@@ -371,3 +371,64 @@ def test_random_nested_scene_parity(pbe, obe, seed):
     ob, ocam, obg = _rand_nested_scene(obe, seed)
     pb, pcam, pbg = _rand_nested_scene(pbe, seed)
     _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, 53 + seed)
+
+
+def _rand_room_scene(be, seed):
+    """Rooms made of parallel pairs of equal AARects (what rt_kernel.hip's rect_pair serves with one division: the Cornell room's
+    left / right walls and floor / ceiling, main.rs:281-286) around boxes and a light: 1-3 pairs on different axes, sometimes a third wall
+    behind a pair (a run of three: pair + single), sometimes two pairs in one run; the camera inside the room, outside it (both walls of
+    a pair in front: the wave takes the two plain tests), or EXACTLY on a wall's plane (numerator 0: `t = 0 < t_min` rejects, no division)."""
+    rs = np.random.RandomState(7000 + seed)
+    b = SceneBuilder(be)
+
+    def col(lo=0.05, hi=0.95):
+        return tuple(float(x) for x in rs.uniform(lo, hi, 3))
+
+    def lam():
+        return b.Lambertian(b.ConstantTexture(col()))
+
+    L = float(rs.choice([100.0, 555.0, 37.5]))
+    world = b.HittableList()
+    glow = b.DiffuseLight(b.ConstantTexture(col(5.0, 15.0)))
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, 0.3 * L, 0.6 * L, 0.35 * L, 0.6 * L, L * (1.0 - 2.0 ** -9), glow))
+    axes = [a for a in (Plane.YZ, Plane.XZ, Plane.XY) if rs.rand() < 0.8] or [Plane.YZ]
+    light_at = rs.randint(0, len(axes) + 1)
+    for n, plane in enumerate(axes):
+        if n == light_at:
+            world.push(lamp)
+        lo, hi = (0.0, L) if rs.rand() < 0.7 else (float(rs.uniform(-0.2, 0.1) * L), float(rs.uniform(0.9, 1.3) * L))
+        ks = [L, 0.0] if rs.rand() < 0.5 else [0.0, L]
+        m1, m2 = lam(), (lam() if rs.rand() < 0.5 else b.Metal(col(0.5, 1.0), float(rs.choice([0.0, 0.2]))))
+        world.push(b.AARect(plane, lo, hi, lo, hi, ks[0], m1))
+        world.push(b.AARect(plane, lo, hi, lo, hi, ks[1], m2))
+        if rs.rand() < 0.3:
+            world.push(b.AARect(plane, lo, hi, lo, hi, float(rs.uniform(1.05, 1.5) * L), lam()))      # a third parallel wall behind: pair + single
+    if light_at >= len(axes):
+        world.push(lamp)
+    for _ in range(rs.randint(0, 3)):
+        sz = rs.uniform(0.15, 0.35, 3) * L
+        box = b.Cube((0.0, 0.0, 0.0), tuple(float(x) for x in sz), lam())
+        world.push(b.Translate(b.Rotate(1, box, float(rs.uniform(-40, 40))), tuple(float(x) for x in rs.uniform(0.1, 0.6, 3) * L)))
+    b.set_scene(world, [lamp] if rs.rand() < 0.8 else [])
+    where = rs.randint(0, 4)
+    if where == 0:      # inside
+        frm = tuple(float(x) for x in rs.uniform(0.2, 0.8, 3) * L)
+    elif where == 1:    # outside, looking in through the open side (or through a wall)
+        frm = (float(rs.uniform(0.3, 0.7) * L), float(rs.uniform(0.3, 0.7) * L), -1.5 * L)
+    elif where == 2:    # exactly on the plane of a wall
+        frm = [float(x) for x in rs.uniform(0.2, 0.8, 3) * L]
+        frm[rs.randint(0, 3)] = float(rs.choice([0.0, L]))
+        frm = tuple(frm)
+    else:               # outside past a corner: two slabs in front
+        frm = (-0.7 * L, 1.6 * L, -0.9 * L)
+    cam = Camera(frm, (0.5 * L, 0.45 * L, 0.55 * L), (0.0, 1.0, 0.0), float(rs.uniform(35, 70)), 1.0, float(rs.choice([0.0, 0.0, 0.02 * L])), L, 0.0, 1.0)
+    return b, cam, col(0.0, 0.3)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_random_room_scene_parity(pbe, obe, seed):
+    ob, ocam, obg = _rand_room_scene(obe, seed)
+    pb, pcam, pbg = _rand_room_scene(pbe, seed)
+    _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, 91 + seed, max_bad=2)
+    info = R.last_launch_info(pb)
+    assert info["threads"] == 256 and info["bvh_nodes"] == 0 and R.last_loop_info(pb)["feats"] == 0, "not the lean list-scene kernel"

@@ -95,6 +95,37 @@ def test_flatten_tables(pbe, earth):
     assert t["triangles"] == 1024 and t["bvh_nodes"] == 2047 and t["rects"] == 6
 
 
+def _objects(pbe, b):
+    pbe.lib.rt_debug_objects.restype = C.c_int
+    pbe.lib.rt_debug_objects.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    n_top = C.c_uint32(0)
+    n = pbe.lib.rt_debug_objects(b.h, None, 0, C.byref(n_top))
+    assert n >= 0
+    out = np.zeros((max(n, 1), 8), np.uint32)
+    assert pbe.lib.rt_debug_objects(b.h, out.ctypes.data, n, C.byref(n_top)) == n
+    return out[:n], int(n_top.value)
+
+
+def test_parallel_rect_pairs_are_marked(pbe):
+    """rt_flatten.cpp marks consecutive rects of a top-level run that have the same plane and the same bounds (rt_kernel.hip rect_pair:
+    one division for the two): the Cornell room's [green, red] and [floor, ceiling, back] -> pairs (0, 1) of each run; nothing else."""
+    ob, n_top = _objects(pbe, build_scene("cornell", pbe)[0])
+    assert n_top == len(ob) == 5
+    assert [tuple(int(x) for x in o[[0, 2, 6, 7]]) for o in ob] == [(0, 2, 2, 1), (0, 1, 0, 0), (0, 3, 2, 1), (0, 6, 1, 0), (0, 6, 1, 0)]
+    b = SceneBuilder(pbe)
+    m = b.Lambertian(b.ConstantTexture((0.5, 0.5, 0.5)))
+    w = b.HittableList()
+    for args in [(Plane.XY, 0, 1, 0, 1, 0.0), (Plane.XY, 0, 1, 0, 1, 2.0), (Plane.XY, 0, 1, 0, 1, 3.0), (Plane.XY, 0, 1, 0, 1, 4.0),   # two pairs
+                 (Plane.XZ, 0, 1, 0, 1, 5.0),                                                                                             # another plane
+                 (Plane.XZ, 0, 1, 0, 2, 6.0),                                                                                             # other bounds
+                 (Plane.XZ, 0, 1, 0, 2, float("inf")), (Plane.XZ, 0, 1, 0, 2, 7.0), (Plane.XZ, 0, 1, 0, 2, 8.0)]:                         # not finite: no pair with it
+        w.push(b.AARect(args[0], float(args[1]), float(args[2]), float(args[3]), float(args[4]), args[5], m))
+    w.push(b.Translate(b.AARect(Plane.XY, 0.0, 1.0, 0.0, 1.0, 9.0, m), (1.0, 0.0, 0.0)))
+    b.set_scene(w, [])
+    ob, n_top = _objects(pbe, b)
+    assert n_top == 2 and tuple(int(x) for x in ob[0][[0, 2, 6, 7]]) == (0, 9, 2, 0b10000101) and int(ob[1][6]) == 0
+
+
 def test_flatten_duplicated_handle_in_a_list(pbe):
     """`list.push(a.clone()); list.push(a)` is legal in the reference: the second occurrence must not stretch the first one's
     primitive range over a neighbouring (or the padding) record."""
@@ -306,6 +337,12 @@ def test_bvh_accepts_every_hittable_kind(kind, pbe, obe):
     leaf_kinds = ((L[:, 0] >> 28) & 7)[(L[:, 0] & LEAF) != 0]
     assert (leaf_kinds == 5).sum() == (3 + 3 if kind == "bvh" else 3)          # G_OBJ: the three children (and, nested, one FlipNormal(Sphere) in each inner BVH)
     assert n_roots.value == (4 if kind == "bvh" else 1)
+    # every sub-object belongs to exactly one G_OBJ leaf: the leaves' runs partition [n_top, n_objects) (a nested BVH's own leaves put
+    # their sub-objects into the table while the BVH is being built as a sub-object of the outer leaf: the runs must not interleave)
+    objs, n_top = _objects(pbe, b)
+    runs = sorted((int(a & 0x0FFFFFFF), int(cnt)) for a, cnt in L[((L[:, 0] & LEAF) != 0) & (((L[:, 0] >> 28) & 7) == 5)][:, :2])
+    assert runs and runs[0][0] == n_top and all(x[0] + x[1] == y[0] for x, y in zip(runs, runs[1:])) and runs[-1][0] + runs[-1][1] == len(objs)
+    assert sorted(r[1] for r in runs) == {"list": [3, 3, 3], "bvh": [1] * 6}.get(kind, [1, 1, 1])
     # 2 top-level objects; the sub-objects behind them: one per child (a list: its three items)
     assert c["objects"] == 2 + {"list": 9, "bvh": 3 + 3}.get(kind, 3)
     eb = np.zeros((n, 6)); fm = C.c_float(0)
