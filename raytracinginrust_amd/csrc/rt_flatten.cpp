@@ -564,7 +564,7 @@ bool flatten_scene(Scene& s) {
     if (!(s.flat.feats & F_NESTED))
         for (uint32_t oi = 0; oi < s.flat.n_top; oi++) {
             DObject& ob = s.flat.objects[oi];
-            if (ob.geom_kind != G_RECT || ob.is_cube != 0u || ob.geom_count < 2u) continue;
+            if (ob.geom_kind != G_RECT || ob.is_cube != 0u || ob.geom_count < 2u || ob.n_ops != 0u || ob.medium >= 0) continue;      // bare runs only: the kernels test them with the path's own ray
             uint32_t mask = 0u;
             for (uint32_t j = 0; j + 1u < ob.geom_count && j < 31u; j++) {
                 const DRect<double>& a = s.flat.rects[ob.geom_first + j];

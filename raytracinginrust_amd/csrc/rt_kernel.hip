@@ -230,6 +230,9 @@ DEV float min3_nn(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, 
 DEV float med3_nn(float a, float b, float c) { float r; asm("v_med3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 DEV float amax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
 
+// f() N times, as straight-line code (a `#pragma unroll` on a loop whose body holds a lambda with LDS reads and ballots is refused by the
+// optimizer for some instantiations — "loop not unrolled", 108 warnings per build until round 6 — although it does unroll the others)
+template <int N, typename F> DEV void repeat(F&& f) { if constexpr (N > 0) { f(); repeat<N - 1>(f); } }
 template <typename T> struct Lim;
 template <> struct Lim<double> { static DEV double max() { return 1.7976931348623157e308; } static DEV double inf() { return __longlong_as_double(0x7FF0000000000000LL); } };
 template <> struct Lim<float> { static DEV float max() { return 3.402823466e38f; } static DEV float inf() { return __uint_as_float(0x7F800000u); } };
@@ -397,38 +400,67 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
 // `t < t_min` rejects the rect for every t_min > 0 without the division being made.  So a rect that is BEHIND the ray (n <= 0 < d_k or
 // d_k < 0 <= n) needs no test, and of a parallel pair at most one is not behind whenever the origin lies between the two planes or on
 // one of them — every ray that starts inside the room or on its walls.  When every lane of the wave has (at least) one of the two behind,
-// the wave runs ONE rect test with a per-lane k — the reference's own division, `o + t d` and bounds test (rect.rs:50-60) on the rect
+// the wave runs ONE rect test with a per-lane k — the reference's own subtraction, division, `o + t d` and bounds test (rect.rs:50-60) on the rect
 // that is not behind — and the other rect's outcome is the rejection derived above: per lane the same sequence of (closest, primitive)
 // updates as the two tests in list order, bit for bit.  A lane with both in front (an origin outside the slab), a NaN anywhere (every
 // comparison above is then false) or t_min <= 0 sends the wave through the two plain tests.
 // Which pairs: rt_flatten.cpp marks them per top-level rect run (DObject::is_cube == 2, mask in DObject::nest).
-template <typename T, uint32_t FEATS> struct PairRule { static constexpr bool on = sizeof(T) == 8u && FEATS == 0u; };
+template <typename T, uint32_t FEATS> struct PairRule { static constexpr bool on = sizeof(T) == 8u && (FEATS & ~(F_BVH | F_TRIS | F_PERSIST | F_NEAR_FIRST)) == 0u; };     // the list-scene and the mesh kernels (rooms)
 // (d_k finite: -inf / inf would be NaN, which rect.rs:51 does not reject; n may be anything — a NaN n fails both comparisons)
 template <typename T> DEV bool rect_behind(T n, T dk) { return ((n <= T(0) && dk > T(0)) || (n >= T(0) && dk < T(0))) && m_abs(dk) <= Lim<T>::max(); }
-template <typename T>
-DEV bool rect_pair_axes(const DRect<T>& r1, T k2, T ok, T dk, T oa, T da, T ob, T db, T t_min, T& closest, bool& second, bool& hit) {
-    const T n1 = r1.k - ok, n2 = k2 - ok;                              // rect.rs:50, the numerators
-    const bool b1 = rect_behind(n1, dk), b2 = rect_behind(n2, dk);
-    if (__ballot(!(b1 || b2)) != 0ull) return false;                   // some lane has both in front (or a NaN): the two plain tests
-    const T t = (b1 ? n2 : n1) / dk;                                   // rect.rs:50 for the rect that is not behind (both behind: this one is rejected just the same)
-    second = b1; hit = false;
-    if (!(t < t_min || t > closest)) {                                 // rect.rs:51-53
-        const T a = oa + t * da, b = ob + t * db;                      // rect.rs:54-55
-        if (!(a < r1.a0 || a > r1.a1 || b < r1.b0 || b > r1.b1)) { closest = t; hit = true; }     // rect.rs:56-58 (the pair's bounds are equal)
-    }
+template <typename T> DEV bool rect_test_k(const DRect<T>& r, T k, T ok, T dk, T oa, T da, T ob, T db, T t_min, T t_max, T& t_out) {   // rect.rs:49-60, the plane's k passed apart
+    T t = (k - ok) / dk;
+    if (t < t_min || t > t_max) return false;
+    T a = oa + t * da;
+    T b = ob + t * db;
+    if (a < r.a0 || a > r.a1 || b < r.b0 || b > r.b1) return false;
+    t_out = t;
     return true;
 }
+// which of the pair (r1 at r1.k, its partner at k2) this lane tests: false when some lane of the wave has both in front (the two plain
+// tests then); otherwise `second` = this lane's r1 is behind, so its partner is the one to test (both behind: the partner is tested and
+// rejected the same way)
 template <typename T>
-DEV bool rect_pair(const DRect<T>& r1, T k2, const RayT<T>& ray, T t_min, T& closest, bool& second, bool& hit) {
-    if (r1.plane == 2u) return rect_pair_axes(r1, k2, ray.o.x, ray.d.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, closest, second, hit);
-    if (r1.plane == 1u) return rect_pair_axes(r1, k2, ray.o.y, ray.d.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, closest, second, hit);
-    return rect_pair_axes(r1, k2, ray.o.z, ray.d.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, closest, second, hit);
+DEV bool rect_pair_pick(const DRect<T>& r1, T k2, const RayT<T>& ray, bool& second) {
+    const T ok = r1.plane == 2u ? ray.o.x : (r1.plane == 1u ? ray.o.y : ray.o.z), dk = r1.plane == 2u ? ray.d.x : (r1.plane == 1u ? ray.d.y : ray.d.z);   // rect.rs:26-32 (wave-uniform)
+    const bool b1 = rect_behind(r1.k - ok, dk), b2 = rect_behind(k2 - ok, dk);     // rect.rs:50, the numerators
+    second = b1;
+    return __ballot(!(b1 || b2)) == 0ull;
+}
+
+// A top-level run of rects in which rt_flatten.cpp marked parallel pairs (bit j of `pairs`: rects j and j + 1), under HittableList::hit
+// (hit.rs:59-71): a loop of its own, so that the plain rect loop of range_hit — which every other object takes — keeps its shape.
+template <typename T>
+DEV bool pair_run_hit(const KParams<T>& P, uint32_t first, uint32_t count, uint32_t pairs, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+    bool any = false;
+    T closest = t_max;
+    for (uint32_t j = 0; j < count; j++) {
+        const DRect<T> r1 = ld_rect(P.rects + first + j);
+        T kk = r1.k;                                                        // (plain scalars, not a modified copy of the record: the compiler would
+        uint32_t idx = first + j;                                           // select among a struct's fields through an address, i.e. in scratch)
+        if (((pairs >> j) & 1u) != 0u && t_min > T(0)) {                    // wave-uniform
+            const T k2 = cl(&P.rects[first + j + 1u].k);
+            bool second;
+            if (rect_pair_pick(r1, k2, ray, second)) {
+                kk = second ? k2 : r1.k;                                     // the rect each lane tests: its own k, the pair's plane and bounds
+                idx += second ? 1u : 0u;
+                j++;                                                         // both records are done
+            }
+        }
+        T t; bool hit;                                                      // rect.rs:49-60 with k = kk
+        if (r1.plane == 2u) hit = rect_test_k(r1, kk, ray.o.x, ray.d.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, closest, t);
+        else if (r1.plane == 1u) hit = rect_test_k(r1, kk, ray.o.y, ray.d.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, closest, t);
+        else hit = rect_test_k(r1, kk, ray.o.z, ray.d.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, closest, t);
+        if (hit) { closest = t; prim_out = (G_RECT << 28) | idx; any = true; }
+    }
+    t_out = closest;
+    return any;
 }
 
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
-DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false, uint32_t pairs = 0u) {
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false) {
     bool any = false;
     T closest = t_max;
     if constexpr (CubeFast<T, FEATS>::on) {
@@ -445,17 +477,6 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
             __builtin_amdgcn_sched_barrier(0);
             const DRect<T> nxt = ld_rect(P.rects + i + 1);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PairRule<T, FEATS>::on) {
-                if (((pairs >> (i - first)) & 1u) != 0u && t_min > T(0)) {            // wave-uniform: this rect and the next are a parallel pair
-                    bool second, hit;
-                    if (rect_pair(cur, nxt.k, ray, t_min, closest, second, hit)) {
-                        if (hit) { prim_out = (G_RECT << 28) | (i + (second ? 1u : 0u)); any = true; }
-                        i++;                                                          // both records are done
-                        cur = ld_rect(P.rects + i + 1);
-                        continue;
-                    }
-                }
-            }
             T t;
 #ifdef RT_DIAG_RECTS    // (its own build: the two atomics per test distort RT_DIAG's timings) how often a rect test could be skipped for the whole
                         // wave by a filter on t: stats[14] tests, [15] with no lane in range
@@ -696,8 +717,7 @@ DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
                 node = (pass && !ahead) ? nd.info : nd.skip;
             };
             if (want_box) box_step();
-#pragma unroll
-            for (int k = 1; k < BOX_STEPS; k++) if (st_walking(node)) box_step();
+            repeat<BOX_STEPS - 1>([&]() { if (st_walking(node)) box_step(); });
         }
     };
     for (;;) {
@@ -823,7 +843,7 @@ DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_
         if constexpr (NEST <= RT_MAX_NEST) return bvh_hit<T, FEATS, NEST>(P, ob.geom_first, r, t_min, t_max, t, prim, stack, rng, sub);
         else return false;              // (the flattener refuses BVHs nested deeper)
     }
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube == 1u, ob.is_cube == 2u ? ob.nest : 0u);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube == 1u);
 }
 // One object under HittableList::hit in an F_NESTED kernel — a top-level object (NEST 0) or a sub-object of a BVH leaf (NEST >= 1; `ray` is
 // then the ray as the enclosing BVH received it: the first n_outer ops of the object's chain are already in it).  Same arithmetic as
@@ -881,8 +901,14 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
     }
     if (FEATS == 0u && ob.n_ops == 0u) {        // no wrapper: test the path's own ray (no copy of it into the registers the wrappers rewrite)
         T t; uint32_t prim;
+        if constexpr (PairRule<T, FEATS>::on) {  // a run of rects with parallel pairs (rt_flatten.cpp marks them on wrapper-less objects only): one copy of that loop
+            if (ob.is_cube == 2u) { if (pair_run_hit<T>(P, ob.geom_first, ob.geom_count, ob.nest, ray, t_min, closest, t, prim)) { closest = t; id.obj = oi; id.prim = prim; any = true; } return; }
+        }
         if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
         return;
+    }
+    if constexpr (PairRule<T, FEATS>::on && FEATS != 0u) {      // (the mesh kernels have the general form only)
+        if (ob.is_cube == 2u) { T t; uint32_t prim; if (pair_run_hit<T>(P, ob.geom_first, ob.geom_count, ob.nest, ray, t_min, closest, t, prim)) { closest = t; id.obj = oi; id.prim = prim; any = true; } return; }
     }
     RayT<T> r = ray;
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
@@ -1913,12 +1939,11 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
                         n_steps++; n_step_lanes += n_box;
                         auto box_step = [&]() { const DFNode nd = fetch_fnode<ALL>(P, tv_node); tv_node = filter_pass(nd, F) ? nd.info : nd.skip; };
                         if (want_box) box_step();
-#pragma unroll
-                        for (int k = 1; k < BOX_STEPS_PERSIST; k++) {              // more box steps under the same vote
+                        repeat<BOX_STEPS_PERSIST - 1>([&]() {                     // more box steps under the same vote
                             const bool more = act && st_walking(tv_node);
                             n_steps++; n_step_lanes += (unsigned long long)__popcll(__ballot(more));
                             if (more) box_step();
-                        }
+                        });
                     }
                 };
                 for (;;) {
