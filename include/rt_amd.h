@@ -261,8 +261,8 @@ int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
 /* Test aid (host only, no GPU): the flattened object table, out[8 i ..] = {geometry kind (0 rect, 1 sphere, 2 moving sphere, 3 triangle,
  * 4 BVH root), first primitive / root node, count, first wrapper op, number of wrapper ops, medium index (0xFFFFFFFF: none), is_cube
- * (1: the six rects are one Cube's faces; 2: a run of rects with parallel pairs — bit j of the next word: rects j and j + 1 have the same
- * plane and bounds and are tested as a pair, rt_kernel.hip rect_pair), nest}: the world's top-level objects (HittableList push order,
+ * (1: the six rects are one Cube's faces), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8)}: the
+ * world's top-level objects (HittableList push order,
  * runs of bare primitives merged) first — *n_top_out of them — then the sub-objects BVH leaves of other Hittable kinds refer to.
  * Returns the number of objects or -1. */
 int rt_debug_objects(rt_scene*, uint32_t* out, uint32_t max_objects, uint32_t* n_top_out);
@@ -281,7 +281,9 @@ int rt_debug_filter_nodes(rt_scene*, float* boxes6_out, uint32_t* links2_out, do
  * (boxes: min[3] max[3]; rays: origin[3] direction[3]).  out[i] bit 0: hit by the reference's form; bit 1: by the NaN-free form the
  * leaf steps use for tame rays; bit 2: the ray qualifies for that form (finite 1/d, |origin| < 1e300); bit 3: ray and box are inside the
  * ranges of the box steps' conservative f32 filter (rt_kernel.hip: make_filter); bit 4: that filter lets the box through (it must
- * wherever bit 0 is set; it may elsewhere).  Non-zero on a HIP error. */
+ * wherever bit 0 is set; it may elsewhere); bits 5, 6, 7: for the f32 kernels (RT_F32) — AABB::hit's form in f32 on the inputs rounded to
+ * nearest (what their leaf steps run), tame ray and filter ranges, their filter's verdict (it must pass wherever bit 5 is set).
+ * Non-zero on a HIP error. */
 int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out);
 /* Test aid: Cube::hit (src/cube.rs:14-36: HittableList::hit over six AARects) on the device for n (cube, ray, [t_min, t_max]) triples
  * given as host arrays (boxes: min[3] max[3]; rays: origin[3] direction[3]); rect_m as KParams::rect_m (>= every |coordinate|).

@@ -302,6 +302,9 @@ struct Flattener {
         o.first_op = (uint32_t)f.ops.size(); o.n_ops = (uint32_t)chain.n; o.medium = medium;
         const int med_at = medium >= 0 ? chain.med_at : 0;
         o.nest = (uint32_t)chain.n_outer | ((uint32_t)med_at << 8);
+        bool flips_only = chain.n > 0 && medium < 0;
+        for (int i = 0; i < chain.n; i++) flips_only = flips_only && chain.ops[i].kind == OP_FLIP;
+        if (flips_only) o.nest |= 0x10000u;            // every wrapper is a FlipNormal: the hit test may use the incoming ray as it is
         if (med_at != 0) f.feats |= F_NESTED;          // a ConstantMedium under a wrapper: the all-features kernel's object_hit serves it
         for (int i = 0; i < chain.n; i++) f.ops.push_back(chain.ops[i]);
         target->push_back(o);
@@ -558,23 +561,6 @@ bool flatten_scene(Scene& s) {
         for (const HNode& h : s.nodes) if (h.kind == HNode::CUBE) for (int k = 0; k < 3; k++) ok = ok && h.v[k] <= h.v[3 + k];
         s.flat.rect_m = ok ? m : 0.0f;
     }
-    // Parallel pairs among the rects of a top-level run (rt_kernel.hip: rect_pair): consecutive rects with the same plane and the same
-    // bounds, both finite — the left / right walls and the floor / ceiling of the Cornell room.  Bit j of the mask: rects j and j + 1 of
-    // the run are tested as a pair.  (Not in scenes with sub-objects: DObject::nest means something else there.)
-    if (!(s.flat.feats & F_NESTED))
-        for (uint32_t oi = 0; oi < s.flat.n_top; oi++) {
-            DObject& ob = s.flat.objects[oi];
-            if (ob.geom_kind != G_RECT || ob.is_cube != 0u || ob.geom_count < 2u || ob.n_ops != 0u || ob.medium >= 0) continue;      // bare runs only: the kernels test them with the path's own ray
-            uint32_t mask = 0u;
-            for (uint32_t j = 0; j + 1u < ob.geom_count && j < 31u; j++) {
-                const DRect<double>& a = s.flat.rects[ob.geom_first + j];
-                const DRect<double>& b = s.flat.rects[ob.geom_first + j + 1u];
-                bool fin = true;
-                for (double v : {a.a0, a.a1, a.b0, a.b1, a.k, b.k}) fin = fin && std::isfinite(v);
-                if (fin && a.plane == b.plane && a.a0 == b.a0 && a.a1 == b.a1 && a.b0 == b.b0 && a.b1 == b.b1) { mask |= 1u << j; j++; }
-            }
-            if (mask) { ob.is_cube = 2u; ob.nest = mask; }
-        }
     s.flat_valid = true;
     return true;
 }

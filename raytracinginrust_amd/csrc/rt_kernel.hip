@@ -392,71 +392,6 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
     return true;
 }
 
-// ------------------------------------------------------------------ a parallel pair of AARects: one division instead of two (round 6)
-// Two consecutive rects of a list with the same plane and the same bounds, at k1 and k2 (the Cornell room's left / right walls, its
-// floor / ceiling: main.rs:281-282,285-286).  AARect::hit starts with t = (k - o_k) / d_k and `if t < t_min || t > t_max { return None }`
-// (rect.rs:50-53).  The numerator n = k - o_k is one exact-as-the-reference subtraction; when n and d_k have opposite strict signs, or n
-// is zero and d_k is not (d_k finite), the quotient is negative or a zero of either sign — IEEE division gets the sign right whatever it rounds — and
-// `t < t_min` rejects the rect for every t_min > 0 without the division being made.  So a rect that is BEHIND the ray (n <= 0 < d_k or
-// d_k < 0 <= n) needs no test, and of a parallel pair at most one is not behind whenever the origin lies between the two planes or on
-// one of them — every ray that starts inside the room or on its walls.  When every lane of the wave has (at least) one of the two behind,
-// the wave runs ONE rect test with a per-lane k — the reference's own subtraction, division, `o + t d` and bounds test (rect.rs:50-60) on the rect
-// that is not behind — and the other rect's outcome is the rejection derived above: per lane the same sequence of (closest, primitive)
-// updates as the two tests in list order, bit for bit.  A lane with both in front (an origin outside the slab), a NaN anywhere (every
-// comparison above is then false) or t_min <= 0 sends the wave through the two plain tests.
-// Which pairs: rt_flatten.cpp marks them per top-level rect run (DObject::is_cube == 2, mask in DObject::nest).
-template <typename T, uint32_t FEATS> struct PairRule { static constexpr bool on = sizeof(T) == 8u && (FEATS & ~(F_BVH | F_TRIS | F_PERSIST | F_NEAR_FIRST)) == 0u; };     // the list-scene and the mesh kernels (rooms)
-// (d_k finite: -inf / inf would be NaN, which rect.rs:51 does not reject; n may be anything — a NaN n fails both comparisons)
-template <typename T> DEV bool rect_behind(T n, T dk) { return ((n <= T(0) && dk > T(0)) || (n >= T(0) && dk < T(0))) && m_abs(dk) <= Lim<T>::max(); }
-template <typename T> DEV bool rect_test_k(const DRect<T>& r, T k, T ok, T dk, T oa, T da, T ob, T db, T t_min, T t_max, T& t_out) {   // rect.rs:49-60, the plane's k passed apart
-    T t = (k - ok) / dk;
-    if (t < t_min || t > t_max) return false;
-    T a = oa + t * da;
-    T b = ob + t * db;
-    if (a < r.a0 || a > r.a1 || b < r.b0 || b > r.b1) return false;
-    t_out = t;
-    return true;
-}
-// which of the pair (r1 at r1.k, its partner at k2) this lane tests: false when some lane of the wave has both in front (the two plain
-// tests then); otherwise `second` = this lane's r1 is behind, so its partner is the one to test (both behind: the partner is tested and
-// rejected the same way)
-template <typename T>
-DEV bool rect_pair_pick(const DRect<T>& r1, T k2, const RayT<T>& ray, bool& second) {
-    const T ok = r1.plane == 2u ? ray.o.x : (r1.plane == 1u ? ray.o.y : ray.o.z), dk = r1.plane == 2u ? ray.d.x : (r1.plane == 1u ? ray.d.y : ray.d.z);   // rect.rs:26-32 (wave-uniform)
-    const bool b1 = rect_behind(r1.k - ok, dk), b2 = rect_behind(k2 - ok, dk);     // rect.rs:50, the numerators
-    second = b1;
-    return __ballot(!(b1 || b2)) == 0ull;
-}
-
-// A top-level run of rects in which rt_flatten.cpp marked parallel pairs (bit j of `pairs`: rects j and j + 1), under HittableList::hit
-// (hit.rs:59-71): a loop of its own, so that the plain rect loop of range_hit — which every other object takes — keeps its shape.
-template <typename T>
-DEV bool pair_run_hit(const KParams<T>& P, uint32_t first, uint32_t count, uint32_t pairs, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
-    bool any = false;
-    T closest = t_max;
-    for (uint32_t j = 0; j < count; j++) {
-        const DRect<T> r1 = ld_rect(P.rects + first + j);
-        T kk = r1.k;                                                        // (plain scalars, not a modified copy of the record: the compiler would
-        uint32_t idx = first + j;                                           // select among a struct's fields through an address, i.e. in scratch)
-        if (((pairs >> j) & 1u) != 0u && t_min > T(0)) {                    // wave-uniform
-            const T k2 = cl(&P.rects[first + j + 1u].k);
-            bool second;
-            if (rect_pair_pick(r1, k2, ray, second)) {
-                kk = second ? k2 : r1.k;                                     // the rect each lane tests: its own k, the pair's plane and bounds
-                idx += second ? 1u : 0u;
-                j++;                                                         // both records are done
-            }
-        }
-        T t; bool hit;                                                      // rect.rs:49-60 with k = kk
-        if (r1.plane == 2u) hit = rect_test_k(r1, kk, ray.o.x, ray.d.x, ray.o.y, ray.d.y, ray.o.z, ray.d.z, t_min, closest, t);
-        else if (r1.plane == 1u) hit = rect_test_k(r1, kk, ray.o.y, ray.d.y, ray.o.x, ray.d.x, ray.o.z, ray.d.z, t_min, closest, t);
-        else hit = rect_test_k(r1, kk, ray.o.z, ray.d.z, ray.o.x, ray.d.x, ray.o.y, ray.d.y, t_min, closest, t);
-        if (hit) { closest = t; prim_out = (G_RECT << 28) | idx; any = true; }
-    }
-    t_out = closest;
-    return any;
-}
-
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
@@ -607,6 +542,11 @@ template <typename T> DEV DBvhNode<T> fetch_node(const KParams<T>& P, uint32_t n
 // Ranges (else the wave takes the exact walk): o, inv finite, |o_j| <= 2^40, 2^-40 <= |inv_j| <= 2^40, every box finite, min <= max,
 // M <= 2^40 (host: KParams::filter_m, >= 1): products stay below 2^82 and E_j above 2^-62, so no overflow, and an underflow (< 2^-126)
 // anywhere is far inside E_j.  A NaN closest hit (never seen) converts to a quiet NaN, which v_min_f32 ignores: conservative.
+// The f32 kernels (RT_F32, T = float) walk the same filter tree; their LEAF test is the exact form in f32 on the node's coordinates rounded
+// to NEAREST (the outward-rounded filter box contains those too): near_j = fl32(fl32(m - o_j) inv_j) is within 2.01 u (|m| + |o_j|) |inv_j|
+// of the real value — u, not 2^-53, so it no longer hides in the slack — and the filter's own terms are as above with inv32 = inv and
+// nx = fl32(-(o_j inv_j)) (one rounding, where the f64 kernels have a product and a conversion): 3.1 u + 2.01 u = 5.11 u of (M + |o_j|) |inv_j|
+// plus 1.01 u E_j.  E_j = 7 u (..) there (>= 6.99 u as computed): 1.8 u of slack.  rt_debug_aabb_hit checks both precisions.
 struct BoxFilter { float ix, iy, iz, ax, bx, ay, by, az, bz, tmin, c; bool ok; };
 DEV float up32(double x) { x = x < -3.0e38 ? -3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), 0x1p-23f, f); }      // >= x
 DEV float down32(double x) { x = x > 3.0e38 ? 3.0e38 : x; const float f = (float)x; return __builtin_fmaf(__builtin_fabsf(f), -0x1p-23f, f); }   // <= x
@@ -618,7 +558,7 @@ template <typename T> DEV BoxFilter make_filter(float M, V3<T> o, V3<T> inv, T t
     const float jx = __builtin_fabsf(F.ix), jy = __builtin_fabsf(F.iy), jz = __builtin_fabsf(F.iz);
     const float ox = __builtin_fabsf((float)o.x), oy = __builtin_fabsf((float)o.y), oz = __builtin_fabsf((float)o.z);
     F.ok = M > 0.0f && max3_nn(jx, jy, jz) <= 0x1p40f && min3_nn(jx, jy, jz) >= 0x1p-40f && max3_nn(ox, oy, oz) <= 0x1p40f;
-    const float K = 6.0f * 0x1p-24f;
+    const float K = (sizeof(T) == 8u ? 6.0f : 7.0f) * 0x1p-24f;      // (f32 kernels: the leaf's exact test has an error of its own, see the proof)
     const float ex = __builtin_copysignf((M + ox) * jx * K, F.ix), ey = __builtin_copysignf((M + oy) * jy * K, F.iy), ez = __builtin_copysignf((M + oz) * jz * K, F.iz);
     const float nx = (float)(-(o.x * inv.x)), ny = (float)(-(o.y * inv.y)), nz = (float)(-(o.z * inv.z));
     // the min plane is the near one where inv > 0: it gets -E, the max plane +E; the other way round where inv < 0 (the sign rides on E)
@@ -843,7 +783,7 @@ DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_
         if constexpr (NEST <= RT_MAX_NEST) return bvh_hit<T, FEATS, NEST>(P, ob.geom_first, r, t_min, t_max, t, prim, stack, rng, sub);
         else return false;              // (the flattener refuses BVHs nested deeper)
     }
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube == 1u);
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube != 0u);
 }
 // One object under HittableList::hit in an F_NESTED kernel — a top-level object (NEST 0) or a sub-object of a BVH leaf (NEST >= 1; `ray` is
 // then the ray as the enclosing BVH received it: the first n_outer ops of the object's chain are already in it).  Same arithmetic as
@@ -901,14 +841,8 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
     }
     if (FEATS == 0u && ob.n_ops == 0u) {        // no wrapper: test the path's own ray (no copy of it into the registers the wrappers rewrite)
         T t; uint32_t prim;
-        if constexpr (PairRule<T, FEATS>::on) {  // a run of rects with parallel pairs (rt_flatten.cpp marks them on wrapper-less objects only): one copy of that loop
-            if (ob.is_cube == 2u) { if (pair_run_hit<T>(P, ob.geom_first, ob.geom_count, ob.nest, ray, t_min, closest, t, prim)) { closest = t; id.obj = oi; id.prim = prim; any = true; } return; }
-        }
         if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
         return;
-    }
-    if constexpr (PairRule<T, FEATS>::on && FEATS != 0u) {      // (the mesh kernels have the general form only)
-        if (ob.is_cube == 2u) { T t; uint32_t prim; if (pair_run_hit<T>(P, ob.geom_first, ob.geom_count, ob.nest, ray, t_min, closest, t, prim)) { closest = t; id.obj = oi; id.prim = prim; any = true; } return; }
     }
     RayT<T> r = ray;
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
@@ -2268,11 +2202,23 @@ __global__ void aabb_kat_kernel(uint32_t n, const double* boxes, const double* r
     fn.skip = fn.info = 0u;
     const bool box_ok = m <= 0x1p40f;                  // (a NaN / infinite coordinate fails this: rt_flatten.cpp make_filter_nodes)
     const BoxFilter F = make_filter(box_ok ? m : 0.0f, o, inv, tlim[i * 2], tlim[i * 2 + 1]);
-    out[i] = (exact ? 1 : 0) | (tame ? 2 : 0) | (tame_ray ? 4 : 0) | (F.ok ? 8 : 0) | (filter_pass(fn, F) ? 16 : 0);
+    // the same for the f32 kernels: the exact form in f32 on the box rounded to nearest (what their leaf steps run) against the filter they build
+    DBvhNode<float> nf;
+    for (int k = 0; k < 3; k++) { nf.mn[k] = (float)nd.mn[k]; nf.mx[k] = (float)nd.mx[k]; }
+    nf.a = nf.b = nf.c = nf.skip = 0;
+    const V3<float> of = mk<float>((float)o.x, (float)o.y, (float)o.z), df = mk<float>((float)d.x, (float)d.y, (float)d.z);
+    const V3<float> invf = mk<float>(1.0f / df.x, 1.0f / df.y, 1.0f / df.z);
+    const float tmin_f = (float)tlim[i * 2], tmax_f = (float)tlim[i * 2 + 1];
+    const bool exact_f = box_inside_exact(nf, of, invf, tmin_f, tmax_f);
+    const bool tame_f = ray_is_tame(of, invf);
+    const BoxFilter Ff = make_filter(box_ok ? m : 0.0f, of, invf, tmin_f, tmax_f);
+    out[i] = (exact ? 1 : 0) | (tame ? 2 : 0) | (tame_ray ? 4 : 0) | (F.ok ? 8 : 0) | (filter_pass(fn, F) ? 16 : 0)
+             | (exact_f ? 32 : 0) | ((tame_f && Ff.ok) ? 64 : 0) | (filter_pass(fn, Ff) ? 128 : 0);
 }
 }
 // out[i]: bit 0 = AABB::hit by the exact form, bit 1 = by the NaN-free form, bit 2 = the ray qualifies for the NaN-free form,
-// bit 3 = ray and box are inside the f32 filter's ranges, bit 4 = the filter (rt_kernel.hip: filter_pass) lets the box through.
+// bit 3 = ray and box are inside the f32 filter's ranges, bit 4 = the filter (rt_kernel.hip: filter_pass) lets the box through;
+// bits 5, 6, 7 = the same three for the f32 kernels (the exact form in f32 on the inputs rounded to nearest, their ranges, their filter).
 // boxes: n x (min[3], max[3]); rays: n x (origin[3], direction[3]); tlim: n x (t_min, t_max).  Host pointers.
 extern "C" int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const double* tlim, int* out) {
     if (n == 0) return 0;

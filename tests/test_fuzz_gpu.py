@@ -374,10 +374,11 @@ def test_random_nested_scene_parity(pbe, obe, seed):
 
 
 def _rand_room_scene(be, seed):
-    """Rooms made of parallel pairs of equal AARects (what rt_kernel.hip's rect_pair serves with one division: the Cornell room's
-    left / right walls and floor / ceiling, main.rs:281-286) around boxes and a light: 1-3 pairs on different axes, sometimes a third wall
-    behind a pair (a run of three: pair + single), sometimes two pairs in one run; the camera inside the room, outside it (both walls of
-    a pair in front: the wave takes the two plain tests), or EXACTLY on a wall's plane (numerator 0: `t = 0 < t_min` rejects, no division)."""
+    """Rooms made of parallel pairs of equal AARects (the Cornell room's left / right walls and floor / ceiling, main.rs:281-286) around
+    boxes and a light: 1-3 pairs on different axes, sometimes a third wall behind a pair, sometimes two pairs in one run; the camera
+    inside the room, outside it (both walls of a pair in front), or EXACTLY on a wall's plane (`t = 0 < t_min` rejects).  (Written for
+    round 6's pair rule — one division for the two rects of a pair, exact by the sign of the numerator — which was measured slower and
+    taken out again, docs/history.md; the family stays: rays that start ON rect planes are what a Cornell bounce is.)"""
     rs = np.random.RandomState(7000 + seed)
     b = SceneBuilder(be)
 

@@ -106,24 +106,11 @@ def _objects(pbe, b):
     return out[:n], int(n_top.value)
 
 
-def test_parallel_rect_pairs_are_marked(pbe):
-    """rt_flatten.cpp marks consecutive rects of a top-level run that have the same plane and the same bounds (rt_kernel.hip rect_pair:
-    one division for the two): the Cornell room's [green, red] and [floor, ceiling, back] -> pairs (0, 1) of each run; nothing else."""
+def test_object_table_of_the_cornell_box(pbe):
+    """rt_debug_objects: [green, red] [FlipNormal(light)] [floor, ceiling, back] [box] [box] (runs of bare rects merge; a Cube is marked)."""
     ob, n_top = _objects(pbe, build_scene("cornell", pbe)[0])
     assert n_top == len(ob) == 5
-    assert [tuple(int(x) for x in o[[0, 2, 6, 7]]) for o in ob] == [(0, 2, 2, 1), (0, 1, 0, 0), (0, 3, 2, 1), (0, 6, 1, 0), (0, 6, 1, 0)]
-    b = SceneBuilder(pbe)
-    m = b.Lambertian(b.ConstantTexture((0.5, 0.5, 0.5)))
-    w = b.HittableList()
-    for args in [(Plane.XY, 0, 1, 0, 1, 0.0), (Plane.XY, 0, 1, 0, 1, 2.0), (Plane.XY, 0, 1, 0, 1, 3.0), (Plane.XY, 0, 1, 0, 1, 4.0),   # two pairs
-                 (Plane.XZ, 0, 1, 0, 1, 5.0),                                                                                             # another plane
-                 (Plane.XZ, 0, 1, 0, 2, 6.0),                                                                                             # other bounds
-                 (Plane.XZ, 0, 1, 0, 2, float("inf")), (Plane.XZ, 0, 1, 0, 2, 7.0), (Plane.XZ, 0, 1, 0, 2, 8.0)]:                         # not finite: no pair with it
-        w.push(b.AARect(args[0], float(args[1]), float(args[2]), float(args[3]), float(args[4]), args[5], m))
-    w.push(b.Translate(b.AARect(Plane.XY, 0.0, 1.0, 0.0, 1.0, 9.0, m), (1.0, 0.0, 0.0)))
-    b.set_scene(w, [])
-    ob, n_top = _objects(pbe, b)
-    assert n_top == 2 and tuple(int(x) for x in ob[0][[0, 2, 6, 7]]) == (0, 9, 2, 0b10000101) and int(ob[1][6]) == 0
+    assert [tuple(int(x) for x in o[[0, 2, 4, 6, 7]]) for o in ob] == [(0, 2, 0, 0, 0), (0, 1, 1, 0, 0), (0, 3, 0, 0, 0), (0, 6, 2, 1, 0), (0, 6, 2, 1, 0)]
 
 
 def test_flatten_duplicated_handle_in_a_list(pbe):

@@ -920,6 +920,13 @@ def test_box_filter_is_conservative_on_grazing_rays(pbe):
     assert 0.2 * n < exact[use].sum() < 0.9 * n, "the cases should straddle the boundary"
     culled = use & exact & ((out & 16) == 0)
     assert not culled.any(), f"the f32 filter culled {int(culled.sum())} boxes AABB::hit passes, e.g. case {int(np.flatnonzero(culled)[0])}"
+    # the f32 kernels (RT_F32) walk the same filter tree with their leaf test in f32: their filter (margin 7 u) against THAT test
+    use32 = (out & 64) != 0
+    assert use32.sum() > 0.85 * n
+    exact32 = (out & 32) != 0
+    assert 0.2 * n < exact32[use32].sum() < 0.9 * n
+    culled32 = use32 & exact32 & ((out & 128) == 0)
+    assert not culled32.any(), f"the f32 kernels' filter culled {int(culled32.sum())} boxes their exact test passes, e.g. case {int(np.flatnonzero(culled32)[0])}"
 
 
 def test_cube_fast_path_against_the_six_rect_tests(pbe, obe):

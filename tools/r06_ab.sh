@@ -1,9 +1,10 @@
 #!/bin/bash
-# round 6, on the GPU box: the suite, then the A/B and ablation runs of the round (logs under gpurun_out/)
+# round 6, on the GPU box: the suite, then the A/B runs of the round (logs under gpurun_out/)
 cd /root/repo
-timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r06d_gputests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r06d_gputests.log
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r06e_gputests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/r06e_gputests.log
 P=raytracinginrust_amd/csrc
-echo "=== pair rule A/B (cornell 800x800x256)"; python tools/ab.py --scene cornell --spp 256 --rounds 6 base=$P/librt_amd.so nopair=$P/abx/nopair.so lean4w=$P/abx/lean4w.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_pair_rule_ab.log
-echo "=== pair rule A/B (teapot room 800x800x64)"; python tools/ab.py --scene teapot --spp 64 --rounds 5 base=$P/librt_amd.so nopair=$P/abx/nopair.so 2>&1 | grep -v amdgpu.ids | tee -a gpurun_out/r06_pair_rule_ab.log
-echo "=== C2 ablations"; python tools/ablate_c2.py --spp 256 base=$P/librt_amd.so onearm=$P/abx/onearm.so lightarm=$P/abx/lightarm.so nopair=$P/abx/nopair.so 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_c2_ablations.log
-echo "=== C2 sections (RT_DIAG build)"; RT_WORKLOADS=C2 python tools/diag_sections.py 256 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_diag_sections_C2.log
+for sc in "cornell 256" "random 256" "final 64" "teapot 64"; do set -- $sc
+  V="base=$P/librt_amd.so flush2=$P/abx/flush2.so"; [ $1 = cornell ] && V="$V flipfast=$P/abx/flipfast.so"
+  echo "=== per-lane atomics at the accumulator flush: $1 (spp $2)"; python tools/ab.py --scene $1 --spp $2 --rounds 5 $V 2>&1 | grep -v amdgpu.ids
+done | tee gpurun_out/r06_flush_per_lane_ab.log
+python tests/sweeps/full_frame_sweep.py C5 --minutes 9 --out gpurun_out/r06e_full_frame_C5.json 2>&1 | tail -2

@@ -2,13 +2,16 @@
 import csv, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
-names = {"C1": "`pathtrace_kernel<double, 63 + F_SPEC>` (lock-step, walk-ahead filtered walk, 1024-thread workgroups)", "C2": "`pathtrace_kernel<double, 0>`",
-         "C3": "`pathtrace_kernel<double, 63>`", "C4": "`pathtrace_kernel<double, 261>` (persistent traversal, 768-thread workgroups)", "C5": "`pathtrace_kernel<double, 0>`"}
+notes = {"C1": " (lock-step, walk-ahead filtered walk, 1024-thread workgroups)", "C4": " (persistent traversal, 768-thread workgroups)"}
 for W in ("C1", "C2", "C3", "C4", "C5"):
     d = json.loads(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{W}.json")).read())
     r = d["roofline"]
     pm = {x["counter"]: x["mean_per_dispatch"] for x in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{W}_pmc_summary.csv")))}
     f = lambda k: float(pm[k])
+    # the instantiation is the one the summary was taken on AND the bench line says it launched (round 6: both name it)
+    kern = pm.get("kernel") or d["roofline"]["kernel"]
+    assert "loop" not in d or d["loop"]["kernel"] == kern, (W, d["loop"]["kernel"], kern)
+    names = {W: "`" + kern.replace("rt::", "") + "`" + notes.get(W, "")}
     busy = f("SQ_ACTIVE_INST_VALU") * (f("LAUNCH_WAVES") / 1024) / f("SQ_WAVE_CYCLES"); lanes = f("SQ_THREAD_CYCLES_VALU") / (64 * f("SQ_ACTIVE_INST_VALU"))
     fetch, write = f("FETCH_SIZE") * 1024 / 1e9, f("WRITE_SIZE") * 1024 / 1e9
     gbps = (fetch + write) / (r["kernel_ms"] * 1e-3)
