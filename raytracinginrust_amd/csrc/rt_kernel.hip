@@ -446,6 +446,27 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
     return any;
 }
 
+// The primitives of a BVH leaf (a typed range) under HittableList::hit.  A leaf that is a Cube (6 rects) has the Cube's corners as its box —
+// the very six numbers the faces' records hold (cube.rs:17-24,39-46: rt_flatten.cpp copies both from the one HNode) — so the fast path
+// takes them from the node the leaf step has in registers instead of gathering two rect records behind it: one dependent memory round
+// trip less per Cube leaf step (round 6; the final scene's 400 ground boxes).  An unclear wave takes the six exact tests from the records.
+template <typename T, uint32_t FEATS>
+DEV bool leaf_hit(const KParams<T>& P, const DBvhNode<T>& lf, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
+    const uint32_t kind = (lf.a >> 28) & 7u, first = lf.a & 0x0FFFFFFFu;
+    if constexpr (CubeFast<T, FEATS>::on) {
+        if (kind == G_RECT && lf.b == 6u) {
+            uint32_t face = 0u; bool hit = false, clear;
+            T t = t_max;
+            if (cube_fast<true>(P.rect_m, lf.mn[0], lf.mx[0], lf.mn[1], lf.mx[1], lf.mn[2], lf.mx[2], ray, t_min, t_max, t, face, hit, clear)) {
+                if (hit) { t_out = t; prim_out = (G_RECT << 28) | (first + face); }
+                return hit;
+            }
+            return range_hit<T, FEATS>(P, kind, first, lf.b, ray, t_min, t_max, t_out, prim_out, false);      // the six exact tests (cube.rs:35-37)
+        }
+    }
+    return range_hit<T, FEATS>(P, kind, first, lf.b, ray, t_min, t_max, t_out, prim_out, lf.b == 6u);
+}
+
 // BVH::hit, bvh.rs:77-91: bbox test, then left subtree, then right subtree with t_max shrunk to the left hit.
 // The recursion's t_max at any node equals min(original t_max, closest hit found earlier in DFS order), so one running
 // `closest` over the same sequence of nodes is the same search.  In the reference's fixed order that sequence needs no stack:
@@ -673,12 +694,13 @@ DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
                 if (!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) {                     // aabb.rs:19-36 on the leaf's own box
                     const uint32_t lk = (lf.a >> 28) & 7u;
                     const bool hit = lk == G_OBJ ? subobjects_hit<T, FEATS, NEST>(P, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, rng, t, prim, sub)
-                                                 : range_hit<T, FEATS>(P, lk, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u);
+                                                 : leaf_hit<T, FEATS>(P, lf, ray, t_min, closest, t, prim);
                     if (hit) { closest = t; prim_out = prim; sub_out = lk == G_OBJ ? sub : NO_SUB; any = true; F.c = up32(closest); }
                 }
             } else
-            if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
-                range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
+            if (!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) {                         // aabb.rs:19-36 on the leaf's own box
+                if (leaf_hit<T, FEATS>(P, lf, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
+            }
             if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
             else node = fnode_skip(P, leaf);
         }
@@ -839,7 +861,8 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
             return;
         }
     }
-    if (FEATS == 0u && ob.n_ops == 0u) {        // no wrapper: test the path's own ray (no copy of it into the registers the wrappers rewrite)
+    if (FEATS == 0u && (ob.n_ops == 0u || (ob.nest & 0x10000u) != 0u)) {        // no wrapper, or FlipNormals only (hit.rs:113-119: they change the record, not the ray; rt_flatten.cpp marks such chains):
+                                                                                // test the path's own ray (no copy of it into the registers the wrappers rewrite).  Round 6: the Cornell light, +0.9 %
         T t; uint32_t prim;
         if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
         return;
@@ -1332,8 +1355,22 @@ DEV double wave_sum(double x) {                      // fixed butterfly: determi
 // Lanes with `need` set hold a partial per-pixel sum (acc) for local pixel acc_px.  All partials of one pixel are
 // combined by a masked butterfly and added to out[] by one lane with one f64 atomic per channel (a handful per pixel
 // per frame: this is the kernel's only global write traffic).
-template <typename T, typename A>
+// PER_LANE (the persistent-traversal kernels, round 6): every lane adds its own partial sum with three atomics instead — few lanes change
+// pixel together in an advance pass, and the butterfly costs the same for two lanes as for sixty-four.  *Measured*
+// (profiles/r06_flush_per_lane_ab.log): teapot room +6.7 %; Cornell box +0.3 %, random spheres -1.4 %, final scene -3 ... -7 % — so only there.
+template <typename T, typename A, bool PER_LANE>
 DEV void flush_acc(const KParams<T>& P, bool need, uint32_t acc_px, const A& acc, uint32_t lane, uint32_t& n_flush) {
+    if constexpr (PER_LANE) {
+        const unsigned long long mm = __ballot(need);
+        if (mm == 0ull) return;
+        if (need) {
+            COLD_K;
+            double* o = PK(out) + (size_t)acc_px * 3u;
+            unsafeAtomicAdd(o + 0, acc.get(0)); unsafeAtomicAdd(o + 1, acc.get(1)); unsafeAtomicAdd(o + 2, acc.get(2));
+        }
+        n_flush += (uint32_t)__popcll(mm);                // lane flushes, three atomics each
+        return;
+    }
     unsigned long long m = __ballot(need);
     while (m) {
         COLD_K;
@@ -1730,7 +1767,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         DIAG_ADD(0);
 
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(P, got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, lane, n_flush);
+        flush_acc<T, typename Shape<FEATS>::Acc, false>(P, got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, lane, n_flush);
 
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
@@ -1780,7 +1817,7 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
         }
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
+    flush_acc<T, typename Shape<FEATS>::Acc, false>(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
     unsigned long long* st; { COLD_K; st = stats_row(PK(stats)); }
     unsigned long long live = n_active;
     write_stats(st, lane, n_nonfinite, n_iters, live, n_flush);
@@ -2008,7 +2045,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         const bool got_new = take_new_paths(P, w, lane, q_real, q_u32, phase == PH_NEW, ray, rng, new_px, path_s);
         DIAG_ADD(2);
         // ---- lanes moving on to another pixel hand in their partial sum
-        flush_acc(P, got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, lane, n_flush);
+        flush_acc<T, typename Shape<FEATS>::Acc, true>(P, got_new && acc_px != NONE_PX && acc_px != new_px, acc_px, acc, lane, n_flush);
         if (got_new) {
             if (acc_px != new_px) { acc_px = new_px; acc.set(0, 0.0); acc.set(1, 0.0); acc.set(2, 0.0); }
             path_px = new_px;
@@ -2038,7 +2075,7 @@ DEV void trace_resumable(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t
         DIAG_ADD(4);
     }
     // ---- the queue is empty: hand in what is left
-    flush_acc(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
+    flush_acc<T, typename Shape<FEATS>::Acc, true>(P, acc_px != NONE_PX, acc_px, acc, lane, n_flush);
     unsigned long long* st; { COLD_K; st = stats_row(PK(stats)); }
     write_stats(st, lane, n_nonfinite, n_iters, n_active, n_flush);
     if (st) {

@@ -53,8 +53,9 @@ def main():
         rows = [(0, w.H)]
         if a.minutes > 0:
             t = time.perf_counter()
-            orc.render(ob, ocam, obg, w.W, w.H, w.spp, w.max_depth, nthreads=threads, mode=0, rows=(w.H // 2, w.H // 2 + 1))
-            per_row = time.perf_counter() - t
+            probe = min(w.H, 2 * threads)                 # (the oracle's threads share ROWS: a one-row probe would time one thread)
+            orc.render(ob, ocam, obg, w.W, w.H, w.spp, w.max_depth, nthreads=threads, mode=0, rows=(w.H // 2, w.H // 2 + probe))
+            per_row = (time.perf_counter() - t) / probe
             n_rows = int(min(w.H, max(a.bands, a.minutes * 60.0 / per_row)))
             if n_rows < w.H:
                 per = max(1, n_rows // a.bands)
