@@ -446,27 +446,6 @@ DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t 
     return any;
 }
 
-// The primitives of a BVH leaf (a typed range) under HittableList::hit.  A leaf that is a Cube (6 rects) has the Cube's corners as its box —
-// the very six numbers the faces' records hold (cube.rs:17-24,39-46: rt_flatten.cpp copies both from the one HNode) — so the fast path
-// takes them from the node the leaf step has in registers instead of gathering two rect records behind it: one dependent memory round
-// trip less per Cube leaf step (round 6; the final scene's 400 ground boxes).  An unclear wave takes the six exact tests from the records.
-template <typename T, uint32_t FEATS>
-DEV bool leaf_hit(const KParams<T>& P, const DBvhNode<T>& lf, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out) {
-    const uint32_t kind = (lf.a >> 28) & 7u, first = lf.a & 0x0FFFFFFFu;
-    if constexpr (CubeFast<T, FEATS>::on) {
-        if (kind == G_RECT && lf.b == 6u) {
-            uint32_t face = 0u; bool hit = false, clear;
-            T t = t_max;
-            if (cube_fast<true>(P.rect_m, lf.mn[0], lf.mx[0], lf.mn[1], lf.mx[1], lf.mn[2], lf.mx[2], ray, t_min, t_max, t, face, hit, clear)) {
-                if (hit) { t_out = t; prim_out = (G_RECT << 28) | (first + face); }
-                return hit;
-            }
-            return range_hit<T, FEATS>(P, kind, first, lf.b, ray, t_min, t_max, t_out, prim_out, false);      // the six exact tests (cube.rs:35-37)
-        }
-    }
-    return range_hit<T, FEATS>(P, kind, first, lf.b, ray, t_min, t_max, t_out, prim_out, lf.b == 6u);
-}
-
 // BVH::hit, bvh.rs:77-91: bbox test, then left subtree, then right subtree with t_max shrunk to the left hit.
 // The recursion's t_max at any node equals min(original t_max, closest hit found earlier in DFS order), so one running
 // `closest` over the same sequence of nodes is the same search.  In the reference's fixed order that sequence needs no stack:
@@ -694,13 +673,12 @@ DEV bool bvh_hit_filt(const KParams<T>& P, uint32_t root, const RayT<T>& ray, T 
                 if (!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) {                     // aabb.rs:19-36 on the leaf's own box
                     const uint32_t lk = (lf.a >> 28) & 7u;
                     const bool hit = lk == G_OBJ ? subobjects_hit<T, FEATS, NEST>(P, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, rng, t, prim, sub)
-                                                 : leaf_hit<T, FEATS>(P, lf, ray, t_min, closest, t, prim);
+                                                 : range_hit<T, FEATS>(P, lk, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u);
                     if (hit) { closest = t; prim_out = prim; sub_out = lk == G_OBJ ? sub : NO_SUB; any = true; F.c = up32(closest); }
                 }
             } else
-            if (!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) {                         // aabb.rs:19-36 on the leaf's own box
-                if (leaf_hit<T, FEATS>(P, lf, ray, t_min, closest, t, prim)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
-            }
+            if ((!tame || box_inside_tame(lf, ray.o, inv, t_min, closest)) &&                       // aabb.rs:19-36 on the leaf's own box
+                range_hit<T, FEATS>(P, (lf.a >> 28) & 7u, lf.a & 0x0FFFFFFFu, lf.b, ray, t_min, closest, t, prim, lf.b == 6u)) { closest = t; prim_out = prim; any = true; F.c = up32(closest); }
             if (SPEC && p1 != ST_DONE) { p1 = ST_DONE; if (st_pending(node)) { p1 = node & ~FNODE_LEAF; node = fnode_skip(P, p1); } }   // the second one moves up; the walk goes on behind it
             else node = fnode_skip(P, leaf);
         }
