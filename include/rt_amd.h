@@ -261,7 +261,8 @@ int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
 /* Test aid (host only, no GPU): the flattened object table, out[8 i ..] = {geometry kind (0 rect, 1 sphere, 2 moving sphere, 3 triangle,
  * 4 BVH root), first primitive / root node, count, first wrapper op, number of wrapper ops, medium index (0xFFFFFFFF: none), is_cube
- * (1: the six rects are one Cube's faces), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8)}: the
+ * (1: the six rects are one Cube's faces), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8; bit 16:
+ * every wrapper is a FlipNormal)}: the
  * world's top-level objects (HittableList push order,
  * runs of bare primitives merged) first — *n_top_out of them — then the sub-objects BVH leaves of other Hittable kinds refer to.
  * Returns the number of objects or -1. */
