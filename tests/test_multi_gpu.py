@@ -216,7 +216,7 @@ def test_bench_runs_one_process_per_gpu_under_the_launcher():
     env = dict(os.environ, RT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     env.pop("RT_MULTI_VIRTUAL_RANKS", None)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29631",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--also", "C1"],
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--also", "C1,C4"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.strip().splitlines() if l.startswith("{")]
@@ -231,6 +231,12 @@ def test_bench_runs_one_process_per_gpu_under_the_launcher():
     assert mc["ok"] and mc["rows"] == [400, 401]
     assert rk["ranks_seen"] == 2 and rk["hosts_rank_ids"] == [0, 1] and all(k > 0 for k in rk["kernel_ms"]) and sum(rk["local_samples"]) == 800 * 800 * 1024
     assert d["workloads"]["C1"]["multi_check"]["ok"]
+    # round 6: the mesh scene's loop shape is measured by rank 0 before anything is timed and handed to the other rank (rt_scene_calibrate,
+    # a broadcast, rt_scene_set_loop_shape): the line says which instantiation ran and why, and both ranks' shares assemble to the frame
+    c4 = d["workloads"]["C4"]
+    assert c4["multi_check"]["ok"] and c4["loop"]["chosen_by"] == "calibration of this view" and c4["loop"]["calibration_ms"]["persistent"] > 0
+    assert c4["loop"]["kernel"] in ("rt::pathtrace_kernel<double, 261u>", "rt::pathtrace_kernel<double, 5u>") and c4["loop"]["kernel"] in c4["kernel"]
+    assert d["loop"]["shape"] == "list" and d["loop"]["kernel"] == "rt::pathtrace_kernel<double, 0u>"
     # (two ranks share the one GPU here, so `multi_ok` — which asks for N distinct devices — is false by design on this box)
     assert d["multi_ok"] is False and rk["devices"] == [0, 0]
 
