@@ -118,7 +118,12 @@ int rt_flip_normal(rt_scene*, int hittable);                                    
 int rt_translate(rt_scene*, int hittable, const double offset[3]);                                     /* Translate::new, src/translate.rs:13  */
 int rt_rotate(rt_scene*, int axis, int hittable, double angle_deg);                                    /* Rotate::new, src/rotate.rs:32        */
 int rt_constant_medium(rt_scene*, int boundary, double density, int texture);                          /* ConstantMedium::new, src/medium.rs:17 */
-int rt_bvh(rt_scene*, const int* hittables, uint32_t n, double time0, double time1);                   /* BVH::new, src/bvh.rs:18              */
+/* BVH::new, src/bvh.rs:18-73: `hittables` may be handles of ANY kind, as the reference's Vec<Box<dyn Hittable>> — bare primitives, lists,
+ * FlipNormal / Translate / Rotate of anything (a Rotate child has the whole-space box of src/rotate.rs:40-57: such a tree is walked with
+ * the exact box test everywhere), ConstantMedium, another BVH (one level of BVHs inside BVH leaves; deeper is an error at flatten time).
+ * Errors where the reference panics: n = 0 ("no object in the scene", src/bvh.rs:55); a child without a bounding box — an empty list or a
+ * wrapper of one ("no bounding box in bvh node", src/bvh.rs:28,61) — at flatten time. */
+int rt_bvh(rt_scene*, const int* hittables, uint32_t n, double time0, double time1);
 int rt_bvh_of_list(rt_scene*, int list, double time0, double time1);                                   /* BVH::new(list.list, ..), src/main.rs:442 */
 
 /* the (world, lights) pair every scene fn returns, src/main.rs:153,278,348,453 */
