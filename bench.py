@@ -330,15 +330,16 @@ def main():
         return b, cam, bg
 
     def settle_loop_shape(b, cam, bg, w):
-        """Mesh scenes: fix the loop shape before anything is timed.  The asynchronous entry points the steps use never measure it
+        """Before anything is timed: the view-dependent choices the asynchronous entry points never make themselves (rt_scene_calibrate).
+        Mesh scenes: fix the loop shape.  The asynchronous entry points the steps use never measure it
         themselves (they would have to wait), so: --loop auto measures it here for this very view — on rank 0's device, and every
         rank then runs what rank 0 found (ranks measuring alone could disagree and the line could not say what ran)."""
         if args.loop != "auto":
-            R.set_loop_shape(b, 1 if args.loop == "persistent" else 0)
-            return
-        if rank == 0:
-            R.calibrate(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags)
-        if world > 1:
+            R.set_loop_shape(b, 1 if args.loop == "persistent" else 0)      # (the call below then measures no loop shape; it still tunes a one-BVH world's filter tree)
+        # (every rank calls it: for a world that is ONE BVH — C1 — the call tunes the filter tree for the view, host arithmetic that every
+        # rank's copy of the scene wants; a mesh scene's four calibration launches run on every rank side by side and rank 0's verdict counts)
+        R.calibrate(b, cam, bg, w.W, w.H, w.spp, w.max_depth, flags=flags)
+        if world > 1 and args.loop == "auto":
             ch = torch.tensor([R.stored_loop_shape(b) if rank == 0 else -1], dtype=torch.int64, device=cdev)
             dist.broadcast(ch, src=0)
             if rank != 0 and int(ch.item()) >= 0:

@@ -227,6 +227,10 @@ int rt_scene_prepare(rt_scene*, uint32_t flags);
  * is calibrated itself; a change to the scene forgets everything).  A no-op for every other kind of scene and for a view already
  * measured.  rt_render, rt_render_samples and rt_render_multi do this themselves at a scene's first frame of >= 1e8 samples;
  * rt_render_device and rt_render_multi_device — asynchronous — never do.
+ * The same call (and the same three synchronous entry points, for every new view) tunes the filter tree of a world that is ONE bare BVH —
+ * the random-spheres scene — for the view: which inner nodes the kernels' box steps skip over is decided by the nodes' estimated pass
+ * rates (a few thousand rays through the tree on the host, < 1 ms) instead of by box areas; random spheres +6 %, samples unchanged
+ * (rt_flatten.cpp tune_filter_tree).
  * rt_scene_set_loop_shape: 1 persistent traversal, 0 lock-step, for every view until the scene changes, -1 forgets (how the ranks of a
  * one-process-per-GPU job all run the shape rank 0 measured).
  * rt_last_loop_info: what the most recent launch ran — out4[0] loop shape (0: a list scene's kernel, 1: lock-step BVH, 2: persistent
@@ -264,6 +268,10 @@ int rt_last_leaf_steps(rt_scene*, unsigned long long out2[2]);
 /* Diagnostic builds (-DRT_DIAG) only (zeros in a normal build): [0..5] wave-cycle sums of the six kernel sections, [6] rect tests
  * counted per wavefront, [7] those among them in which no lane's plane distance lay in [t_min, closest] (-DRT_DIAG_RECTS builds). */
 int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
+/* Test aid (host only, no GPU): what rt_scene_calibrate does to the filter tree of a world that is ONE bare BVH — inner nodes leave it by
+ * their estimated pass rate for the view instead of by box areas (rt_flatten.cpp tune_filter_tree; scheduling only: any conservative
+ * hierarchy over the leaves gives the same samples) — without touching a device copy.  1: rebuilt, 0: not that kind of scene, -1: error. */
+int rt_debug_tune_filter(rt_scene*, const rt_camera*);
 /* Test aid (host only, no GPU): the flattened object table, out[8 i ..] = {geometry kind (0 rect, 1 sphere, 2 moving sphere, 3 triangle,
  * 4 BVH root), first primitive / root node, count, first wrapper op, number of wrapper ops, medium index (0xFFFFFFFF: none), is_cube
  * (1: the six rects are one Cube's faces), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8; bit 16:

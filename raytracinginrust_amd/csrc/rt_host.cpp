@@ -340,6 +340,16 @@ int rt_scene_flatten(rt_scene* sc, uint32_t counts[12]) {
     return 0;
 }
 
+// Test aid (host only, no GPU): tune the filter tree of a one-BVH world for a view (rt_flatten.cpp tune_filter_tree) without touching any
+// device copy; 1 if the tree was rebuilt, 0 if the scene is not of that kind, -1 on error.  rt_debug_filter_nodes then shows the result.
+int rt_debug_tune_filter(rt_scene* sc, const rt_camera* cam) {
+    if (!sc || !cam) return set_err("null argument");
+    if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    rt_camera_args ca; std::memcpy(&ca, cam, sizeof(ca));
+    DCamera<double> dcam; camera_new(ca, dcam);
+    return tune_filter_tree(sc->s, dcam) ? 1 : 0;
+}
+
 // Test aid (host only): the flattened object table, out[8*i ..] = object i's {geom_kind, geom_first, geom_count, first_op, n_ops, medium,
 // is_cube, nest} (rt_ir.h DObject): the world's top-level objects first, then the sub-objects of G_OBJ leaves.  Returns the number of
 // objects (all of them), *n_top_out the number of top-level ones; -1 on error.
@@ -742,6 +752,27 @@ int check_frame_args(rt_scene* sc, const rt_camera* cam, const double* bg, uint3
     return 0;
 }
 
+// Worlds that are ONE bare BVH: tune the filter tree's contraction for this view (rt_flatten.cpp tune_filter_tree: host arithmetic, < 1 ms)
+// and refresh every device copy of the filter nodes.  SYNCHRONOUS (it waits for the scene's launches before it overwrites a table they
+// read), so it runs where calibrate_loop_shape runs: rt_scene_calibrate and the synchronous entry points, once per view; a no-op for
+// every other scene.  Samples do not depend on it (any conservative hierarchy over the leaves gives the reference's).
+static int tune_for_view(Scene& s, const rt_camera* cam, uint32_t W, uint32_t H) {
+    const unsigned long long key = loop_view_key(cam, W, H, 0u);
+    if (s.filter_key == key) return 0;
+    s.filter_key = key;
+    rt_camera_args ca; std::memcpy(&ca, cam, sizeof(ca));
+    DCamera<double> dcam; camera_new(ca, dcam);
+    if (!tune_filter_tree(s, dcam)) return 0;
+    if (settle_all_launches(s)) return -1;
+    std::vector<DFNode> fn(s.flat.bvh_f); fn.push_back(DFNode{});
+    for (Scene::DeviceCtx* c : s.ctxs) {
+        DeviceGuard guard(c->device);
+        if (c->dev64.valid && c->dev64.bvh_f) HIP_OK(hipMemcpy(c->dev64.bvh_f, fn.data(), fn.size() * sizeof(DFNode), hipMemcpyHostToDevice));
+        if (c->dev32.valid && c->dev32.bvh_f) HIP_OK(hipMemcpy(c->dev32.bvh_f, fn.data(), fn.size() * sizeof(DFNode), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
 // Mesh scenes: which loop shape is faster depends on what the rays of THIS view do inside the trees (a closed surface that fills a third
 // of the frame: the persistent loop by 10 %; a sparse cloud of triangles in a corner: the lock-step loop by 10 ... 80 %), not on anything
 // the flattener can see.  Both give the same samples bit for bit, so a calibration renders the same view at <= 1024 x 1024 x 16 twice in
@@ -800,7 +831,7 @@ int render_any(rt_scene* sc, const rt_camera* cam, const double bg[3], uint32_t 
     if (tile_px == 0 || world == 0 || rank >= world) return set_err("bad tile decomposition");
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
-    if (may_calibrate && calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, stream, true)) return -1;
+    if (may_calibrate && (tune_for_view(sc->s, cam, W, H) || calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, stream, true))) return -1;
     if (flags & RT_F32) return render_impl<float>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
     return render_impl<double>(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, tile_px, rank, world, d_out, d_out_bytes, d_samples, stream);
 }
@@ -821,6 +852,7 @@ int rt_scene_calibrate(rt_scene* sc, const rt_camera* cam, const double bg[3], u
     if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    if (tune_for_view(sc->s, cam, W, H)) return -1;
     return calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, nullptr, false);
 }
 int rt_scene_set_loop_shape(rt_scene* sc, int shape) {
@@ -857,6 +889,7 @@ int calibrate_if_worth_it(rt_scene* sc, const rt_camera* cam, const double bg[3]
     if (check_frame_args(sc, cam, bg, W, H, spp)) return -1;
     if (rt_device_count() <= 0) return set_err("no HIP device: librt_amd has no CPU rendering path");
     if (!flatten_scene(sc->s)) { g_err = sc->s.error; return -1; }
+    if (tune_for_view(sc->s, cam, W, H)) return -1;
     return calibrate_loop_shape(sc->s, cam, bg, W, H, spp, max_depth, seed, flags, nullptr, true);
 }
 // rt_scene_prepare's work for one device context; the calling thread's current HIP device must be c.device and the scene must be

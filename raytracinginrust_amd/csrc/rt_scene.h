@@ -71,6 +71,9 @@ struct Scene {
     // FEATS template argument of the instantiation, [2] how the shape was chosen (0 the scene leaves no choice, 1 size rule, 2 calibration,
     // 3 the caller's RT_PERSISTENT_BVH / RT_LOCKSTEP_BVH flag, 4 rt_scene_set_loop_shape), [3] precision (0 f64, 1 f32)
     int last_loop[4] = {0, 0, 0, 0};
+    // Worlds that are ONE bare BVH: the view whose estimated pass rates the filter tree's contraction was last tuned for (0: the area
+    // rule's tree as flattened) — rt_flatten.cpp tune_filter_tree, rt_host.cpp tune_for_view; any tree gives the same samples
+    unsigned long long filter_key = 0;
     std::vector<int> lights;
     std::string error;
 
@@ -129,7 +132,7 @@ struct Scene {
     // debugging aid (rt_debug_trace_path; -DRT_TRACE_PATH builds of the kernels): the path whose hits are recorded, and the device buffer
     long long trace_px = -1, trace_s = -1; void* d_trace = nullptr; int trace_device = -1; uint32_t trace_levels = 0;     // trace_levels: 16-double records d_trace holds
 
-    void invalidate() { flat_valid = false; loop_choice = -1; loop_how = 0; loop_ms[0] = loop_ms[1] = 0.f; }
+    void invalidate() { flat_valid = false; loop_choice = -1; loop_how = 0; loop_ms[0] = loop_ms[1] = 0.f; filter_key = 0; }
     DeviceCtx& ctx_for(int device) {
         for (DeviceCtx* c : ctxs) if (c->device == device) return *c;
         DeviceCtx* c = new DeviceCtx(); c->device = device; ctxs.push_back(c); return *c;
@@ -139,6 +142,8 @@ struct Scene {
 
 // rt_flatten.cpp
 bool flatten_scene(Scene& s);
+template <typename T> struct DCamera;
+bool tune_filter_tree(Scene& s, const DCamera<double>& cam);      // one-BVH worlds: contraction by a view's estimated pass rates; true if the filter tree was rebuilt
 // rt_host.cpp (shared with rt_multi.cpp)
 int set_error(const std::string& m);                              // leaves the message for rt_last_error(); returns -1
 int device_kernel_ms(Scene& s, int device, float* ms);            // duration of the last path-tracing kernel launched on `device`

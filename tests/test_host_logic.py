@@ -379,7 +379,7 @@ def test_bvh_skip_links_thread_the_recursions_order(name, pbe, earth):
     assert seen.all()                                             # every node belongs to exactly the trees walked
 
 
-@pytest.mark.parametrize("name", ["random", "final", "teapot"])
+@pytest.mark.parametrize("name", ["random", "final", "teapot", "random tuned for its view"])
 def test_filter_tree_is_a_conservative_hierarchy_over_the_same_leaves(name, pbe, earth):
     """The f64 kernels' box steps walk the FILTER tree (rt_ir.h DFNode; rt_flatten.cpp make_filter_nodes): f32 boxes and links from which
     near-duplicate inner nodes have been taken out.  What makes that exact (rt_kernel.hip: the ordered-scan form of BVH::hit) is checked
@@ -387,8 +387,26 @@ def test_filter_tree_is_a_conservative_hierarchy_over_the_same_leaves(name, pbe,
     box test passing the filter walk meets exactly the leaves of the reference tree, each once, in the reference's depth-first order;
     (3) every node the filter walk can stand at contains every leaf it reaches before that node's skip link — culling a node never
     skips a leaf outside it; (4) contraction did take nodes out (and never a leaf or a root)."""
-    b, _, _ = build_scene(name, pbe, earth)
+    tuned = name.endswith("tuned for its view")
+    b, cam, _ = build_scene(name.split()[0], pbe, earth)
     n = R.flatten(b)["bvh_nodes"]
+    if tuned:
+        # round 6: worlds that are ONE bare BVH get their contraction from a view's estimated pass rates (rt_flatten.cpp tune_filter_tree,
+        # what rt_scene_calibrate and the synchronous renders do): the tree it leaves must pass the very same checks
+        pbe.lib.rt_debug_tune_filter.restype = C.c_int
+        pbe.lib.rt_debug_tune_filter.argtypes = [C.c_void_p, C.c_void_p]
+        before = np.zeros((n, 2), np.uint32)
+        pbe.lib.rt_debug_filter_nodes.restype = C.c_int
+        pbe.lib.rt_debug_filter_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+        assert pbe.lib.rt_debug_filter_nodes(b.h, None, before.ctypes.data, None, n, None) == n
+        assert pbe.lib.rt_debug_tune_filter(b.h, C.byref(cam)) == 1
+        after = np.zeros((n, 2), np.uint32)
+        assert pbe.lib.rt_debug_filter_nodes(b.h, None, after.ctypes.data, None, n, None) == n
+        assert not np.array_equal(before, after)                               # another set of nodes left the tree
+        for other in ("final", "teapot", "cornell"):                           # scenes whose BVHs stand beside other objects (or have none) are left alone
+            ob, ocam, _ = build_scene(other, pbe, earth)
+            R.flatten(ob)
+            assert pbe.lib.rt_debug_tune_filter(ob.h, C.byref(ocam)) == 0
     links = (C.c_uint32 * (4 * n))(); roots = (C.c_uint32 * 8)(); n_roots = C.c_uint32(0)
     assert pbe.lib.rt_debug_bvh_links(b.h, links, n, roots, 8, C.byref(n_roots)) == n
     L = np.frombuffer(links, np.uint32).reshape(n, 4)

@@ -838,6 +838,54 @@ def test_loop_shape_of_a_mesh_scene_is_measured(pbe, monkeypatch):
     assert li5 == {"shape": "list", "feats": 0, "kernel": "rt::pathtrace_kernel<double, 0u>", "chosen_by": "the scene leaves no choice", "calibration_ms": None}
 
 
+def test_view_tuned_filter_tree_is_scheduling_only(pbe, monkeypatch):
+    """Worlds that are ONE bare BVH (random spheres) get the contraction of their filter tree from a view's estimated pass rates — at the
+    first synchronous render of a view, or by rt_scene_calibrate (rt_host.cpp tune_for_view, rt_flatten.cpp tune_filter_tree).  Any
+    conservative hierarchy over the leaves gives the reference's samples: every sample bit-identical with the area rule's tree
+    (RT_NO_FILTER_TUNING), for the view the tree was tuned for and for another one; the asynchronous entry point keeps the tree it finds."""
+    import ctypes as C
+    W, H, spp, depth = 64, 48, 8, 8
+    lib = pbe.lib
+    lib.rt_debug_filter_nodes.restype = C.c_int
+    lib.rt_debug_filter_nodes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]
+
+    def links(b):
+        n = R.flatten(b)["bvh_nodes"]
+        fl = np.zeros((n, 2), np.uint32)
+        assert lib.rt_debug_filter_nodes(b.h, None, fl.ctypes.data, None, n, None) == n
+        return fl
+
+    monkeypatch.setenv("RT_NO_FILTER_TUNING", "1")
+    b0, cam0, bg0 = scenes.random_scene(pbe, aspect_ratio=W / H)
+    _, plain = R.render(b0, cam0, bg0, W, H, spp, depth, want_samples=True)
+    area_tree = links(b0)
+    monkeypatch.delenv("RT_NO_FILTER_TUNING")
+    b1, cam1, bg1 = scenes.random_scene(pbe, aspect_ratio=W / H)
+    assert np.array_equal(links(b1), area_tree)                                # as flattened: the area rule
+    _, tuned = R.render(b1, cam1, bg1, W, H, spp, depth, want_samples=True)   # the first render of a view tunes the tree for it
+    assert not np.array_equal(links(b1), area_tree)
+    assert np.array_equal(plain.view(np.uint64), tuned.view(np.uint64))
+    assert R.last_loop_info(b1)["feats"] == 2111
+    # another view: re-tuned (synchronous entry point), same samples as the area rule's tree gives for that view
+    cam2 = Camera((3.0, 6.0, 13.0), (0.0, 0.5, 0.0), (0.0, 1.0, 0.0), 35.0, W / H, 0.0, 10.0, 0.0, 1.0)
+    t1 = links(b1)
+    _, tuned2 = R.render(b1, cam2, bg1, W, H, spp, depth, want_samples=True)
+    assert not np.array_equal(links(b1), t1)
+    monkeypatch.setenv("RT_NO_FILTER_TUNING", "1")                             # (read at every tune)
+    _, plain2 = R.render(b0, cam2, bg0, W, H, spp, depth, want_samples=True)
+    assert np.array_equal(links(b0), area_tree)
+    monkeypatch.delenv("RT_NO_FILTER_TUNING")
+    assert np.array_equal(plain2.view(np.uint64), tuned2.view(np.uint64))
+    # the asynchronous entry point never tunes: a fresh scene rendered through it keeps the area rule's tree until the caller calibrates
+    b3, cam3, bg3 = scenes.random_scene(pbe, aspect_ratio=W / H)
+    R.render_multi_device(b3, cam3, bg3, W, H, spp, depth, device_mask=1); R.multi_sync(b3)
+    assert np.array_equal(links(b3), area_tree)
+    R.calibrate(b3, cam3, bg3, W, H, spp, depth)
+    assert not np.array_equal(links(b3), area_tree)
+    got = R.render_multi(b3, cam3, bg3, W, H, spp, depth, device_mask=1)
+    assert np.all(np.abs(got - plain.sum(axis=2)) <= 1e-12 * (spp + np.abs(plain.sum(axis=2))))
+
+
 def _big_mesh_room(be, n_tris):
     rs = np.random.RandomState(5)
     b = SceneBuilder(be)
