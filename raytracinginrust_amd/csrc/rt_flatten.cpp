@@ -555,6 +555,7 @@ bool tune_filter_tree(Scene& s, const DCamera<double>& cam) {
     HostFlat& f = s.flat;
     if (std::getenv("RT_NO_FILTER_TUNING")) return false;                 // A/B runs
     if (f.n_top != 1 || f.objects[0].geom_kind != G_BVH || f.objects[0].n_ops != 0 || f.objects[0].medium >= 0 || (f.feats & F_NESTED)) return false;
+    if ((f.feats & F_PBR) || (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) == 0u) return false;      // (the scenes the walk-ahead kernel serves: what was measured; a bare mesh was not)
     const size_t n = f.bvh.size();
     if (n < 64 || f.filter_m == 0.0f) return false;
     const uint32_t DONE = 0xFFFFFFFFu, root = f.objects[0].geom_first;
