@@ -26,6 +26,13 @@ utilisation, and it is flagged when it exceeds what HBM could deliver.  Physical
 (`valu_pmc`) come from the committed rocprofv3 --pmc passes of this same command and are used only when that profile was taken on
 THIS build of the kernels and launch code (matching `kernel_source_id`); otherwise they are null.
 
+`loop` (headline and every workload): what ran — loop shape, the instantiation's FEATS and name as a profiler shows it, how the shape was
+chosen, the calibration's two kernel times (rt_last_loop_info).  Before anything is timed every workload's view is calibrated
+(rt_scene_calibrate: mesh scenes measure their loop shape — rank 0's verdict is handed to every rank —, one-BVH worlds tune their filter
+tree; `--loop persistent|lockstep` sets the shape instead, which is what the profiled runs of tools/profile_all.sh do).  PMC-derived fields
+are replayed only from a committed profile of this build AND this instantiation; `roofline.frac` is reference-equivalent throughput,
+`roofline.executed_valu_frac` what the SIMDs really issue.
+
 `workloads`: the other BASELINE configs (C1, C3, C4, C5) timed the same way, one reduced-spp warm-up frame + one full frame each
 (twenty for C1, whose frame is a few milliseconds), so that every config's Msamples/s and roofline fraction is on the driver's clock.
 
