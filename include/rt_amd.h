@@ -274,7 +274,11 @@ int rt_debug_section_cycles(rt_scene*, unsigned long long out8[8]);
 int rt_debug_tune_filter(rt_scene*, const rt_camera*);
 /* Test aid (host only, no GPU): the flattened object table, out[8 i ..] = {geometry kind (0 rect, 1 sphere, 2 moving sphere, 3 triangle,
  * 4 BVH root), first primitive / root node, count, first wrapper op, number of wrapper ops, medium index (0xFFFFFFFF: none), is_cube
- * (1: the six rects are one Cube's faces), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8; bit 16:
+ * (1: the six rects are one Cube's faces; 2 | map << 8: a ROOM — bare AARects of a list scene that are exact faces of one axis-aligned box,
+ * searched as one object where the last of them stood, through the Cube fast path with a face map: three bits per face in cube.rs:17-24
+ * order = the wall's place in the room's run of rect records, 7 = no such wall; first_op then holds five bits per wall, the index of the
+ * first object that stood after that wall and is searched before the room — an exact tie with an object at or beyond it goes to that
+ * object, as hit.rs:62-68 gives it to the later item; rt_flatten.cpp form_room), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8; bit 16:
  * every wrapper is a FlipNormal)}: the
  * world's top-level objects (HittableList push order,
  * runs of bare primitives merged) first — *n_top_out of them — then the sub-objects BVH leaves of other Hittable kinds refer to.

@@ -398,6 +398,105 @@ struct Flattener {
         return fail("unknown node kind");
     }
 
+    // ---- a ROOM: bare AARects of the world list that are exact faces of ONE axis-aligned box become one object (list scenes only)
+    // HittableList::hit over n such walls is n exact rect tests — n f64 divisions for every lane of a wave; as faces of a box they are what
+    // Cube::hit's fast path decides with ONE exact test (rt_kernel.hip: cube_fast, ROOM form; the Cornell room's five walls: *measured*
+    // tools/room_as_cube_probe.py, six walls as one Cube +6.7 %).  What makes it exact:
+    //   * a wall joins only if its record IS a face of the box: its plane coordinate equals the box's min or max on that axis and its two
+    //     ranges equal the box's, bit for bit; no wrapper, no medium, at most one wall per face, every axis with min < max; the walls keep
+    //     their list order inside the room's run of records (copies: the originals stay where lights and other objects refer to them);
+    //     a run of bare rects that gives only some of its rects keeps the others, each stretch of them as an object where it stood;
+    //   * HittableList::hit returns the hit with the smallest t, the later item on an exact tie (hit.rs:59-71) — a function of the items'
+    //     own hits and their ORDER, not of the sequence in which they are tried, as long as no item's test depends on the closest hit
+    //     beyond `t <= closest` (true of rects, Cubes and wrapped ones; a ConstantMedium draws from the RNG by it, a BVH has none here:
+    //     rooms are formed only when the scene has neither — feats == 0, the list-scene kernels).  The room is tried where its LAST wall
+    //     stood, so every object that stood between two walls is tried before them; a tie between a wall and such an object that came
+    //     AFTER the wall must still go to the object: per wall, the new index of the first object that came after it (five bits each in
+    //     first_op, which a wrapper-less object does not use) — the kernel rejects a wall's hit on an exact tie with an object at or
+    //     beyond that index (rt_kernel.hip: object_hit).
+    // At least four walls (three exact tests cost what the fast path's approximate phase does); RT_NO_ROOM (A/B runs, tests) turns it off.
+    void form_room() {
+        if (f.feats != 0u || !subs.empty() || std::getenv("RT_NO_ROOM")) return;
+        const uint32_t n = (uint32_t)f.objects.size();
+        // the list, item by item: a run of bare rects is the rects it holds (HittableList[a, b] is a then b), anything else is itself
+        struct Item { uint32_t obj; int rect; };                // rect < 0: the whole object, not a candidate
+        std::vector<Item> items;
+        for (uint32_t i = 0; i < n; i++) {
+            const DObject& o = f.objects[i];
+            const bool bare_rects = o.geom_kind == G_RECT && o.n_ops == 0u && o.medium < 0 && o.is_cube == 0u && o.nest == 0u;
+            if (bare_rects) for (uint32_t r = 0; r < o.geom_count; r++) items.push_back({i, (int)(o.geom_first + r)});
+            else items.push_back({i, -1});
+        }
+        auto axes = [](uint32_t plane, int& k, int& a, int& b) { k = 2 - (int)plane; a = plane == 2u ? 1 : 0; b = plane == 0u ? 1 : 2; };     // rect.rs:26-32
+        std::vector<size_t> cand;                               // items that are bare rects on a known plane, in list order
+        for (size_t x = 0; x < items.size(); x++) if (items[x].rect >= 0 && f.rects[(size_t)items[x].rect].plane <= 2u) cand.push_back(x);
+        std::vector<size_t> best; double bmn[3] = {0, 0, 0}, bmx[3] = {0, 0, 0}; uint32_t best_slot[6] = {7u, 7u, 7u, 7u, 7u, 7u};
+        const size_t n_seed = std::min<size_t>(cand.size(), 48u);       // (the pairs that may define the box: among the first 48 bare rects of the list)
+        for (size_t xi = 0; xi < n_seed; xi++) for (size_t yi = 0; yi < n_seed; yi++) {
+            const size_t x = cand[xi], y = cand[yi];
+            // two walls on different planes fix a box: x gives two ranges and a plane coordinate, y the range of x's plane axis
+            const DRect<double>& rx = f.rects[(size_t)items[x].rect]; const DRect<double>& ry = f.rects[(size_t)items[y].rect];
+            if (rx.plane == ry.plane) continue;
+            int kx, ax, bx, ky, ay, by; axes(rx.plane, kx, ax, bx); axes(ry.plane, ky, ay, by);
+            double mn[3], mx[3];
+            mn[ax] = rx.a0; mx[ax] = rx.a1; mn[bx] = rx.b0; mx[bx] = rx.b1;
+            if (ay == kx) { mn[kx] = ry.a0; mx[kx] = ry.a1; } else if (by == kx) { mn[kx] = ry.b0; mx[kx] = ry.b1; } else continue;
+            bool ok = true;
+            for (int q = 0; q < 3; q++) ok = ok && std::isfinite(mn[q]) && std::isfinite(mx[q]) && mn[q] < mx[q];
+            if (!ok) continue;
+            std::vector<size_t> got; uint32_t slot_of[6] = {7u, 7u, 7u, 7u, 7u, 7u};
+            for (size_t w : cand) {
+                const DRect<double>& r = f.rects[(size_t)items[w].rect];
+                int k, a, b; axes(r.plane, k, a, b);
+                if (!(r.a0 == mn[a] && r.a1 == mx[a] && r.b0 == mn[b] && r.b1 == mx[b])) continue;
+                int face;                                       // cube.rs:17-24: (XY, XZ, YZ) x (max, min)
+                if (r.k == mx[k]) face = 2 * (int)r.plane; else if (r.k == mn[k]) face = 2 * (int)r.plane + 1; else continue;
+                if (slot_of[face] != 7u) continue;              // a second wall on the same face stays an ordinary rect
+                slot_of[face] = (uint32_t)got.size(); got.push_back(w);
+            }
+            if (got.size() > best.size()) {
+                best = got;
+                for (int q = 0; q < 3; q++) { bmn[q] = mn[q]; bmx[q] = mx[q]; }
+                for (int q = 0; q < 6; q++) best_slot[q] = slot_of[q];
+            }
+        }
+        if (best.size() < 4u) return;
+        std::vector<unsigned char> is_wall(items.size(), 0);
+        for (size_t w : best) is_wall[w] = 1;
+        const size_t last = best.back();                        // (`best` is in list order)
+        // the new list: the walls leave, the room stands where the last of them stood, what is left of a run of rects stays where it was
+        // (as one object per stretch of consecutive records)
+        std::vector<DObject> out; std::vector<uint32_t> new_of(items.size(), 0u);
+        uint32_t room_at = 0;
+        for (size_t x = 0; x < items.size(); x++) {
+            if (is_wall[x]) { if (x == last) { room_at = (uint32_t)out.size(); out.push_back(DObject{}); } continue; }
+            const Item& it = items[x];
+            if (it.rect < 0) { new_of[x] = (uint32_t)out.size(); out.push_back(f.objects[it.obj]); continue; }
+            const bool joins = x > 0 && !is_wall[x - 1] && items[x - 1].obj == it.obj && items[x - 1].rect + 1 == it.rect && !out.empty() && x - 1 != last;
+            if (joins) { out.back().geom_count++; new_of[x] = (uint32_t)out.size() - 1u; }
+            else { DObject o = f.objects[it.obj]; o.geom_first = (uint32_t)it.rect; o.geom_count = 1u; new_of[x] = (uint32_t)out.size(); out.push_back(o); }
+        }
+        if (room_at > 31u) return;
+        DObject room{};
+        room.geom_kind = G_RECT; room.geom_first = (uint32_t)f.rects.size(); room.geom_count = (uint32_t)best.size();
+        room.first_op = 0u; room.n_ops = 0u; room.medium = -1; room.nest = 0u;
+        uint32_t map = 0u;
+        for (int q = 0; q < 6; q++) map |= best_slot[q] << (3 * q);
+        room.is_cube = 2u | (map << 8);
+        for (size_t j = 0; j < best.size(); j++) {
+            // the first object that stood AFTER this wall and is tried BEFORE the room (none: the room's own index, which no earlier hit carries)
+            uint32_t thr = room_at;
+            for (size_t x = best[j] + 1u; x < last; x++) if (!is_wall[x]) { thr = new_of[x]; break; }
+            room.first_op |= std::min(thr, 31u) << (5u * (uint32_t)j);
+        }
+        const uint32_t mat0 = f.rects[(size_t)items[best[0]].rect].mat;
+        for (size_t w : best) f.rects.push_back(DRect<double>(f.rects[(size_t)items[w].rect]));
+        f.rects.push_back({bmn[0], bmx[0], bmn[1], bmx[1], bmx[2], 0u, mat0});       // the box, laid out like a Cube's first two faces (never tested, never hit)
+        f.rects.push_back({bmn[0], bmx[0], bmn[1], bmx[1], bmn[2], 0u, mat0});
+        out[room_at] = room;
+        f.objects.swap(out);
+    }
+
     bool run() {
         f = HostFlat{};
         f.materials = s.materials;
@@ -413,6 +512,7 @@ struct Flattener {
         Chain c;
         target = &f.objects;
         if (!emit(s.world, c, -1)) return false;
+        form_room();
         // the sub-objects follow the world's own objects in the one table: G_OBJ leaves learn their final indices
         f.n_top = (uint32_t)f.objects.size();
         if (!subs.empty()) {

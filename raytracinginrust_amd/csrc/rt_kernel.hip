@@ -333,9 +333,16 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
 // nothing was changed), the exact test only when some lane has a face to test.  !WAVE (the device known-answer test): per lane,
 // `clear_out` says whether this lane's outcome was clear.  face_out in cube.rs:17-24 order.  One function, plain scalars: with the box
 // or the classification in a struct the compiler selects among their fields through an ADDRESS, i.e. puts them in scratch memory.
+// ROOM form (round 6; list-scene kernels): the same test for a box of which only SOME faces exist — bare AARects of a list that are exact faces
+// of one axis-aligned box (the Cornell room's five walls; rt_flatten.cpp: form_room).  `map` holds, per face in cube.rs:17-24 order, three
+// bits: the face's place in the room's run of rect records, or 7 = no such face.  The argument above is about the six plane distances and
+// the box, not about which faces exist: for a clear lane only the entry and the exit face of the FULL box could pass their bounds tests,
+// so of the faces that exist the list accepts the entry face if it exists and lies in range, else the exit face if it exists and lies in
+// range, else nothing — an absent face is classed "out of range", whatever its distance.  face_out is then the record's place in the run.
+// map == 0: a Cube, all six faces, face_out in cube.rs order (the code above, unchanged).
 template <bool WAVE>
 DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy, double mnz, double mxz, const RayT<double>& ray, double t_min, double t_max,
-                   double& t_out, uint32_t& face_out, bool& any, bool& clear_out) {
+                   double& t_out, uint32_t& face_out, bool& any, bool& clear_out, uint32_t map = 0u) {
     const float rx = __builtin_amdgcn_rcpf((float)ray.d.x), ry = __builtin_amdgcn_rcpf((float)ray.d.y), rz = __builtin_amdgcn_rcpf((float)ray.d.z);
     // the six plane distances, approximately: the exact numerator k - o_k of rect.rs:50, rounded to f32, times the approximate 1 / d_k
     const float ax0 = (float)(mnx - ray.o.x) * rx, ax1 = (float)(mxx - ray.o.x) * rx;
@@ -353,8 +360,21 @@ DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy,
     const float lo = __builtin_fmaxf((float)t_min, -1.0e37f), hi = __builtin_fminf((float)t_max, 1.0e37f);
     const float gl = RHO * __builtin_fabsf(lo), gh = RHO * __builtin_fabsf(hi);
     const float g1 = RHO * __builtin_fabsf(s1), g2 = RHO * __builtin_fabsf(e1);
-    const bool en_in = s1 - lo > g1 + gl && hi - s1 > g1 + gh, en_out = lo - s1 > g1 + gl || s1 - hi > g1 + gh;
-    const bool ex_in = e1 - lo > g2 + gl && hi - e1 > g2 + gh, ex_out = lo - e1 > g2 + gl || e1 - hi > g2 + gh;
+    bool en_in = s1 - lo > g1 + gl && hi - s1 > g1 + gh, en_out = lo - s1 > g1 + gl || s1 - hi > g1 + gh;
+    bool ex_in = e1 - lo > g2 + gl && hi - e1 > g2 + gh, ex_out = lo - e1 > g2 + gl || e1 - hi > g2 + gh;
+    if (map != 0u) {                                                     // (wave-uniform) a room: which of the two faces exist
+        const bool enx = s1 == nrx, eny = !enx && s1 == nry, exx = e1 == frx, exy = !exx && e1 == fry;
+        // (the sign of d from its f32 reciprocal: the same sign wherever d is not a zero, and the axis of a zero component is never the
+        // entry or exit axis of a clear lane — its plane distances are infinite)
+        const float den_en = enx ? rx : (eny ? ry : rz), den_ex = exx ? rx : (exy ? ry : rz);
+        // the entry plane of an axis is min's where d > 0 and max's where d < 0, the exit plane the other one; (XY, XZ, YZ) x (max, min)
+        const uint32_t sh_en = (enx ? 12u : (eny ? 6u : 0u)) + (den_en < 0.0f ? 0u : 3u), sh_ex = (exx ? 12u : (exy ? 6u : 0u)) + (den_ex < 0.0f ? 3u : 0u);
+        const bool has_en = ((map >> sh_en) & 7u) != 7u, has_ex = ((map >> sh_ex) & 7u) != 7u;
+        // (*measured*, profiles/r06_room_ab.log: the same as lane-mask arithmetic over six wave-uniform "face exists" flags — seven vector
+        // compares, the rest on the scalar unit — is 1.9 % SLOWER: the kernel has no scalar registers to spare either)
+        en_in = en_in && has_en; en_out = en_out || !has_en;
+        ex_in = ex_in && has_ex; ex_out = ex_out || !has_ex;
+    }
     const bool clear = order_clear && (past || (through && (en_in || (en_out && (ex_in || ex_out)))));
     clear_out = clear;
     if (WAVE ? __ballot(!clear) != 0ull : !clear) return false;
@@ -374,6 +394,7 @@ DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy,
             if (!((out_x && !on_x) || (out_y && !on_y) || (out_z && !on_z))) {
                 t_out = t; any = true;
                 face_out = (on_x ? 4u : (on_y ? 2u : 0u)) + (hi_side ? 0u : 1u);                                      // (XY, XZ, YZ) x (max, min)
+                if (map != 0u) face_out = (map >> (3u * face_out)) & 7u;                                              // a room: the record's place in its run
             }
         }
     }
@@ -383,11 +404,14 @@ DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy,
 // the all-features BVH kernels.  *Measured* (round 5, profiles/r05_cube_in_bvh_kernels_ab.log): final scene +4 % with it (400 ground boxes
 // as BVH leaves); the mesh kernels and the one-BVH-world kernel, whose scenes have no Cube, lose 1 % to its registers: left out there.
 template <typename T, uint32_t FEATS> struct CubeFast { static constexpr bool on = sizeof(T) == 8u && ((FEATS & F_BVH) == 0u || ((FEATS & F_SPHERES) != 0u && (FEATS & F_SPEC) == 0u)); };
-DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
-    const DRect<double> f0 = ld_rect(P.rects + first);                  // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
-    const double mnz = cl(&P.rects[first + 1u].k);                      // XY face at z = min.z (cube.rs:18)
+// `room` (DObject::is_cube of a room object: 2 | map << 8; 0 for a Cube): the run holds `count` wall records in the list's order and, behind
+// them, two records that only carry the box — laid out like a Cube's first two faces.
+DEV bool cube_hit(const KParams<double>& P, uint32_t first, uint32_t count, uint32_t room, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
+    const uint32_t box_at = room != 0u ? first + count : first;
+    const DRect<double> f0 = ld_rect(P.rects + box_at);                 // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
+    const double mnz = cl(&P.rects[box_at + 1u].k);                     // XY face at z = min.z (cube.rs:18)
     uint32_t face = 0u; bool hit = false, clear;
-    if (!cube_fast<true>(P.rect_m, f0.a0, f0.a1, f0.b0, f0.b1, mnz, f0.k, ray, t_min, t_max, t_out, face, hit, clear)) return false;
+    if (!cube_fast<true>(P.rect_m, f0.a0, f0.a1, f0.b0, f0.b1, mnz, f0.k, ray, t_min, t_max, t_out, face, hit, clear, room >> 8)) return false;
     if (hit) { any = true; prim_out = (G_RECT << 28) | (first + face); }
     return true;
 }
@@ -395,11 +419,11 @@ DEV bool cube_hit(const KParams<double>& P, uint32_t first, const RayT<double>& 
 // closest accepted hit of a typed primitive range under HittableList semantics (hit.rs:59-71): each item is
 // offered [t_min, closest_so_far]; a later item with t <= closest replaces an earlier one.
 template <typename T, uint32_t FEATS>
-DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false) {
+DEV bool range_hit(const KParams<T>& P, uint32_t kind, uint32_t first, uint32_t count, const RayT<T>& ray, T t_min, T t_max, T& t_out, uint32_t& prim_out, bool is_cube = false, uint32_t room = 0u) {
     bool any = false;
     T closest = t_max;
     if constexpr (CubeFast<T, FEATS>::on) {
-        if (kind == G_RECT && is_cube && cube_hit(P, first, ray, t_min, t_max, closest, prim_out, any)) { t_out = closest; return any; }
+        if (kind == G_RECT && (is_cube || room != 0u) && cube_hit(P, first, count, room, ray, t_min, t_max, closest, prim_out, any)) { t_out = closest; return any; }
     }
     if (kind == G_RECT) {
         // software-pipelined record fetch: record i+1 is requested before record i is tested (the table carries one
@@ -778,12 +802,13 @@ template <typename T> DEV void op_fwd(const DOp<T>& op, RayT<T>& r) {
 // ------------------------------------------------------------------ world.hit: closest hit over the top-level list
 // (sub: the sub-object a hit inside a BVH belongs to when the leaf was a G_OBJ one — F_NESTED kernels; NO_SUB otherwise)
 template <typename T, uint32_t FEATS, int NEST = 0>
-DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack, Rng& rng, uint32_t& sub) {
+DEV bool geom_hit(const KParams<T>& P, const DObject& ob, const RayT<T>& r, T t_min, T t_max, T& t, uint32_t& prim, uint32_t* stack, Rng& rng, uint32_t& sub, bool rooms = false) {
     if ((FEATS & F_BVH) && ob.geom_kind == G_BVH) {
         if constexpr (NEST <= RT_MAX_NEST) return bvh_hit<T, FEATS, NEST>(P, ob.geom_first, r, t_min, t_max, t, prim, stack, rng, sub);
         else return false;              // (the flattener refuses BVHs nested deeper)
     }
-    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube != 0u);
+    // (a room — is_cube & 2 — exists in list scenes only and has no wrappers: one call site knows about it, the others' code is unchanged)
+    return range_hit<T, FEATS>(P, ob.geom_kind, ob.geom_first, ob.geom_count, r, t_min, t_max, t, prim, ob.is_cube != 0u, rooms && (ob.is_cube & 2u) ? ob.is_cube : 0u);
 }
 // One object under HittableList::hit in an F_NESTED kernel — a top-level object (NEST 0) or a sub-object of a BVH leaf (NEST >= 1; `ray` is
 // then the ray as the enclosing BVH received it: the first n_outer ops of the object's chain are already in it).  Same arithmetic as
@@ -842,7 +867,15 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
     if (FEATS == 0u && (ob.n_ops == 0u || (ob.nest & 0x10000u) != 0u)) {        // no wrapper, or FlipNormals only (hit.rs:113-119: they change the record, not the ray; rt_flatten.cpp marks such chains):
                                                                                 // test the path's own ray (no copy of it into the registers the wrappers rewrite).  Round 6: the Cornell light, +0.9 %
         T t; uint32_t prim;
-        if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        if (geom_hit<T, FEATS>(P, ob, ray, t_min, closest, t, prim, stack, rng, no_sub, true)) {
+            // A room stands where the LAST of its walls stood in the list (rt_flatten.cpp: form_room), so an object that stood between two
+            // walls is searched before all of them.  HittableList::hit's result is the hit with the smallest t, the LATER item on an exact
+            // tie (hit.rs:62-68: `t <= closest` accepts); every t is compared as before, only a tie between a wall and an object that came
+            // AFTER it in the list must still go to that object: first_op holds, five bits per wall, the index of the first such object.
+            bool keep = true;
+            if (ob.is_cube & 2u) keep = !(any && t == closest && id.obj >= ((ob.first_op >> (5u * ((prim & 0x0FFFFFFFu) - ob.geom_first))) & 31u));
+            if (keep) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+        }
         return;
     }
     RayT<T> r = ray;

@@ -41,6 +41,28 @@ def flatten(b: SceneBuilder) -> dict:
     return dict(zip(FLATTEN_COUNT_NAMES, [int(x) for x in counts]))
 
 
+OBJECT_FIELDS = ("geom_kind", "geom_first", "geom_count", "first_op", "n_ops", "medium", "is_cube", "nest")
+
+
+def debug_objects(b: SceneBuilder, top_only: bool = True) -> list:
+    """The flattened object table (rt_debug_objects; host only): one dict per object, the world's top-level objects in the order the
+    kernels search them.  is_cube: 1 = a Cube's six faces; 2 | map << 8 = a ROOM (bare AARects that are faces of one box, tested through
+    the Cube fast path: rt_flatten.cpp form_room) — map: three bits per face in cube.rs:17-24 order, the wall's place in the room's run
+    of rect records or 7 = no such wall; first_op then holds, five bits per wall, the tie-rule index."""
+    be = _lib.load()
+    be.lib.rt_debug_objects.restype = C.c_int
+    be.lib.rt_debug_objects.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
+    n_top = C.c_uint32(0)
+    n = be.lib.rt_debug_objects(b.h, None, 0, C.byref(n_top))
+    if n < 0:
+        raise RenderError(_err(be))
+    out = np.zeros((max(n, 1), 8), np.uint32)
+    if be.lib.rt_debug_objects(b.h, out.ctypes.data, n, C.byref(n_top)) != n:
+        raise RenderError(_err(be))
+    rows = out[: (int(n_top.value) if top_only else n)]
+    return [dict(zip(OBJECT_FIELDS, [int(x) for x in r])) for r in rows]
+
+
 RT_BVH_MEDIAN, RT_BVH_SAH = 0, 1
 
 

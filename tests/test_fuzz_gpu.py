@@ -433,3 +433,99 @@ def test_random_room_scene_parity(pbe, obe, seed):
     _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, 91 + seed, max_bad=2)
     info = R.last_launch_info(pb)
     assert info["threads"] == 256 and info["bvh_nodes"] == 0 and R.last_loop_info(pb)["feats"] == 0, "not the lean list-scene kernel"
+
+
+def _rand_box_room_scene(be, seed):
+    """Walls that are EXACT faces of one axis-aligned box — what rt_flatten.cpp's form_room turns into one object tested through the Cube
+    fast path's ROOM form (round 6: the Cornell room's five walls, main.rs:291-296) — in a random list order, 3 to 6 of the six faces
+    (three: no room is formed), between and around them whatever can stand in a list scene: the lamp, rotated boxes, a bare Cube, and
+    the things that TIE with a wall bit for bit — a patch in a wall's own plane (bare, or under a FlipNormal), a second wall on the
+    same face — placed before, between and after the walls, so that HittableList::hit's later-item-wins rule (hit.rs:62-68) decides
+    samples whichever way the room's index-aware tie rule could get wrong.  Cameras: inside, outside looking through an absent face,
+    outside looking at a wall's back, on a wall's plane, in a corner, on an edge line of the box."""
+    rs = np.random.RandomState(9100 + seed)
+    b = SceneBuilder(be)
+
+    def col(lo=0.05, hi=0.95):
+        return tuple(float(x) for x in rs.uniform(lo, hi, 3))
+
+    def mat():
+        return b.Lambertian(b.ConstantTexture(col())) if rs.rand() < 0.75 else b.Metal(col(0.5, 1.0), float(rs.choice([0.0, 0.3])))
+
+    L = float(rs.choice([100.0, 555.0, 12.5]))
+    mn = np.array([0.0, 0.0, 0.0]) if rs.rand() < 0.5 else rs.uniform(-0.5, 0.3, 3) * L
+    mx = mn + rs.uniform(0.6, 1.4, 3) * L
+    axes = {Plane.XY: (2, 0, 1), Plane.XZ: (1, 0, 2), Plane.YZ: (0, 1, 2)}       # plane -> (k, a, b) axes, rect.rs:26-32
+
+    def face(plane, hi, m):
+        k, a_, b_ = axes[plane]
+        return b.AARect(plane, float(mn[a_]), float(mx[a_]), float(mn[b_]), float(mx[b_]), float(mx[k] if hi else mn[k]), m)
+
+    def patch(plane, hi, m):
+        """a smaller rect in the same plane as a face: every hit on it ties with the wall's, bit for bit"""
+        k, a_, b_ = axes[plane]
+        lo_a, hi_a = sorted(rs.uniform(0.1, 0.9, 2)); lo_b, hi_b = sorted(rs.uniform(0.1, 0.9, 2))
+        ext_a, ext_b = mx[a_] - mn[a_], mx[b_] - mn[b_]
+        return b.AARect(plane, float(mn[a_] + lo_a * ext_a), float(mn[a_] + hi_a * ext_a), float(mn[b_] + lo_b * ext_b), float(mn[b_] + hi_b * ext_b),
+                        float(mx[k] if hi else mn[k]), m)
+
+    all_faces = [(p, h) for p in (Plane.XY, Plane.XZ, Plane.YZ) for h in (True, False)]
+    n_faces = int(rs.choice([3, 4, 5, 5, 5, 6]))
+    chosen = [all_faces[i] for i in rs.permutation(6)[:n_faces]]
+    glow = b.DiffuseLight(b.ConstantTexture(col(4.0, 15.0)))
+    ky = mx[1] - (mx[1] - mn[1]) * 2.0 ** -9
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, float(mn[0] + 0.3 * (mx[0] - mn[0])), float(mn[0] + 0.6 * (mx[0] - mn[0])),
+                                 float(mn[2] + 0.35 * (mx[2] - mn[2])), float(mn[2] + 0.6 * (mx[2] - mn[2])), float(ky), glow))
+    items = [face(p, h, mat()) for p, h in chosen]
+    extras = [lamp]
+    for _ in range(rs.randint(0, 4)):
+        p, h = all_faces[rs.randint(0, 6)]
+        kind = rs.randint(0, 4)
+        if kind == 0:
+            extras.append(patch(p, h, mat()))                                   # a bare patch: joins a run of rects, never a wall
+        elif kind == 1:
+            extras.append(b.FlipNormal(patch(p, h, mat())))                     # a wrapped patch: an object of its own
+        elif kind == 2:
+            extras.append(face(p, h, mat()))                                    # a second (or first) wall on a face: ties everywhere
+        else:
+            extras.append(b.FlipNormal(face(p, h, mat())))
+    for _ in range(rs.randint(0, 3)):
+        sz = rs.uniform(0.15, 0.35, 3) * (mx - mn)
+        box = b.Cube((0.0, 0.0, 0.0), tuple(float(x) for x in sz), mat())
+        at = tuple(float(x) for x in mn + rs.uniform(0.1, 0.55, 3) * (mx - mn))
+        extras.append(b.Translate(b.Rotate(1, box, float(rs.uniform(-40, 40))), at) if rs.rand() < 0.7 else
+                      b.Cube(at, tuple(float(x) for x in np.array(at) + sz), mat()))
+    for e in extras:                                                            # anywhere in the list: before, between, after the walls
+        items.insert(rs.randint(0, len(items) + 1), e)
+    world = b.HittableList()
+    for it in items:
+        world.push(it)
+    b.set_scene(world, [lamp] if rs.rand() < 0.8 else [])
+    ctr, ext = 0.5 * (mn + mx), mx - mn
+    where = rs.randint(0, 6)
+    if where == 0:      # inside
+        frm = mn + rs.uniform(0.2, 0.8, 3) * ext
+    elif where == 1:    # outside, in front of one face (absent: looks in; present: looks at its back)
+        frm = ctr.copy(); ax = rs.randint(0, 3); frm[ax] = (mn[ax] - 1.5 * ext[ax]) if rs.rand() < 0.5 else (mx[ax] + 1.5 * ext[ax])
+    elif where == 2:    # exactly on the plane of a face
+        frm = mn + rs.uniform(0.2, 0.8, 3) * ext; ax = rs.randint(0, 3); frm[ax] = mn[ax] if rs.rand() < 0.5 else mx[ax]
+    elif where == 3:    # outside past a corner
+        frm = mn - rs.uniform(0.5, 1.2, 3) * ext
+    elif where == 4:    # exactly in a corner of the box
+        frm = np.where(rs.rand(3) < 0.5, mn, mx)
+    else:               # on the line of an edge, outside
+        frm = mn.copy(); frm[rs.randint(0, 3)] -= 0.8 * L
+    at = ctr + rs.uniform(-0.1, 0.1, 3) * ext
+    cam = Camera(tuple(float(x) for x in frm), tuple(float(x) for x in at), (0.0, 1.0, 0.0), float(rs.uniform(35, 80)), 1.0,
+                 float(rs.choice([0.0, 0.0, 0.02 * L])), float(L), 0.0, 1.0)
+    return b, cam, col(0.0, 0.3), n_faces
+
+
+@pytest.mark.parametrize("seed", list(range(32)))
+def test_random_box_room_scene_parity(pbe, obe, seed):
+    ob, ocam, obg, _ = _rand_box_room_scene(obe, seed)
+    pb, pcam, pbg, n_faces = _rand_box_room_scene(pbe, seed)
+    _compare_with_oracle(pb, pcam, pbg, ob, ocam, obg, 131 + seed, max_bad=2)
+    assert R.last_loop_info(pb)["feats"] == 0, "not the lean list-scene kernel"
+    rooms = [o for o in R.debug_objects(pb) if o["is_cube"] & 2]
+    assert len(rooms) == 1 or (n_faces < 4 and not rooms), (n_faces, rooms)    # (three chosen faces: a room only if an extra wall stands on a fourth)

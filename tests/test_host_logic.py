@@ -83,9 +83,9 @@ def test_write_ppm_layout(tmp_path, pbe):
 
 def test_flatten_tables(pbe, earth):
     c = R.flatten(build_scene("cornell", pbe)[0])
-    # 6 wall/light rects + 2 x 6 cube faces; runs of bare rects merge into one typed range each:
-    # [green, red] [FlipNormal(light)] [floor, ceiling, back] [box] [box]
-    assert (c["objects"], c["ops"], c["rects"], c["lights"], c["bvh_nodes"]) == (5, 5, 18, 1, 0)
+    # 6 wall/light rects + 2 x 6 cube faces; the five walls are faces of one box: one ROOM object where the last of them stood (round 6;
+    # its run of rect records = copies of the five + two records that carry the box): [FlipNormal(light)] [room] [box] [box]
+    assert (c["objects"], c["ops"], c["rects"], c["lights"], c["bvh_nodes"]) == (4, 5, 18 + 5 + 2, 1, 0)
     r = R.flatten(build_scene("random", pbe)[0])
     assert r["spheres"] + r["moving_spheres"] == 533 and r["bvh_nodes"] == 2 * 533 - 1 and r["lights"] == 0
     f = R.flatten(build_scene("final", pbe, earth)[0])
@@ -106,11 +106,89 @@ def _objects(pbe, b):
     return out[:n], int(n_top.value)
 
 
-def test_object_table_of_the_cornell_box(pbe):
-    """rt_debug_objects: [green, red] [FlipNormal(light)] [floor, ceiling, back] [box] [box] (runs of bare rects merge; a Cube and a FlipNormal-only chain are marked)."""
+def test_object_table_of_the_cornell_box(pbe, monkeypatch):
+    """rt_debug_objects: [FlipNormal(light)] [room: the five walls] [box] [box] — and, with RT_NO_ROOM, the list as the reference has it:
+    [green, red] [FlipNormal(light)] [floor, ceiling, back] [box] [box] (runs of bare rects merge; a Cube and a FlipNormal-only chain are marked)."""
+    ob, n_top = _objects(pbe, build_scene("cornell", pbe)[0])
+    assert n_top == len(ob) == 4
+    assert [tuple(int(x) for x in o[[0, 2, 4, 7]]) for o in ob] == [(0, 1, 1, 0x10000), (0, 5, 0, 0), (0, 6, 2, 0), (0, 6, 2, 0)]      # 0x10000: every wrapper of the light is a FlipNormal (the lean kernel tests the path's own ray)
+    room = ob[1]
+    assert int(room[1]) == 18 and int(room[6]) & 0xFF == 2 and int(ob[0][6]) == 0 and int(ob[2][6]) == int(ob[3][6]) == 1
+    # faces in cube.rs:17-24 order (z max, z min, y max, y min, x max, x min) -> place in the run, which keeps main.rs:291-296's order
+    # [x = 555 green, x = 0 red, y = 0 floor, y = 555 ceiling, z = 555 back]; 7: the open front
+    assert [(int(room[6]) >> (8 + 3 * f)) & 7 for f in range(6)] == [4, 7, 3, 2, 0, 1]
+    # the tie rule: the light (new index 0) stood after the first two walls and before the other three (whose entry is the room's own index)
+    assert [(int(room[3]) >> (5 * j)) & 31 for j in range(5)] == [0, 0, 1, 1, 1]
+    monkeypatch.setenv("RT_NO_ROOM", "1")
     ob, n_top = _objects(pbe, build_scene("cornell", pbe)[0])
     assert n_top == len(ob) == 5
-    assert [tuple(int(x) for x in o[[0, 2, 4, 6, 7]]) for o in ob] == [(0, 2, 0, 0, 0), (0, 1, 1, 0, 0x10000), (0, 3, 0, 0, 0), (0, 6, 2, 1, 0), (0, 6, 2, 1, 0)]      # 0x10000: every wrapper of the light is a FlipNormal (the lean kernel tests the path's own ray)
+    assert [tuple(int(x) for x in o[[0, 2, 4, 6, 7]]) for o in ob] == [(0, 2, 0, 0, 0), (0, 1, 1, 0, 0x10000), (0, 3, 0, 0, 0), (0, 6, 2, 1, 0), (0, 6, 2, 1, 0)]
+
+
+def _room_list(pbe, spec, lights=False):
+    """A list scene from a compact spec: ("w", plane, hi) a wall of the box (0,0,0)-(4,6,8) on that face, ("p", plane, hi) a smaller
+    patch in a face's plane, ("r", ...) a rect that is no face at all, ("f", item) a FlipNormal around an item, ("c",) a rotated Cube."""
+    b = SceneBuilder(pbe)
+    m = b.Lambertian(b.ConstantTexture((0.5, 0.5, 0.5)))
+    mn, mx = (0.0, 0.0, 0.0), (4.0, 6.0, 8.0)
+    ax = {Plane.XY: (2, 0, 1), Plane.XZ: (1, 0, 2), Plane.YZ: (0, 1, 2)}
+
+    def make(it):
+        if it[0] == "w":
+            k, a_, b_ = ax[it[1]]
+            return b.AARect(it[1], mn[a_], mx[a_], mn[b_], mx[b_], mx[k] if it[2] else mn[k], m)
+        if it[0] == "p":
+            k, a_, b_ = ax[it[1]]
+            return b.AARect(it[1], mn[a_] + 1.0, mx[a_] - 1.0, mn[b_] + 1.0, mx[b_] - 1.0, mx[k] if it[2] else mn[k], m)
+        if it[0] == "r":
+            return b.AARect(Plane.XY, -1.0, 1.0, -1.0, 1.0, 20.0, m)
+        if it[0] == "f":
+            return b.FlipNormal(make(it[1]))
+        return b.Translate(b.Rotate(1, b.Cube((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), m), 10.0), (1.0, 1.0, 1.0))
+
+    world = b.HittableList()
+    for it in spec:
+        world.push(make(it))
+    b.set_scene(world, [])
+    return b
+
+
+def test_rooms_are_formed_from_exact_faces_only(pbe):
+    """rt_flatten.cpp form_room: which rects of a list become a room, where it stands, what stays, and the tie-rule indices."""
+    XY, XZ, YZ = Plane.XY, Plane.XZ, Plane.YZ
+    rooms = lambda b: [o for o in R.debug_objects(b) if o["is_cube"] & 2]
+    # three walls: not worth it; four: a room
+    assert rooms(_room_list(pbe, [("w", XY, True), ("w", XZ, True), ("w", YZ, True)])) == []
+    t = R.debug_objects(_room_list(pbe, [("w", XY, True), ("w", XZ, True), ("w", YZ, True), ("w", YZ, False)]))
+    assert len(t) == 1 and t[0]["is_cube"] & 2 and t[0]["geom_count"] == 4 and t[0]["first_op"] == 0
+    assert [(t[0]["is_cube"] >> (8 + 3 * f)) & 7 for f in range(6)] == [0, 7, 1, 7, 2, 3]
+    # things between the walls are searched first, in their order; every wall learns the first of them that stood after it
+    spec = [("c",), ("w", YZ, True), ("f", ("p", XY, True)), ("w", YZ, False), ("w", XZ, False), ("c",), ("w", XY, True), ("c",)]
+    t = R.debug_objects(_room_list(pbe, spec))
+    assert [(o["n_ops"], bool(o["is_cube"] & 2)) for o in t] == [(2, False), (1, False), (2, False), (0, True), (2, False)]
+    assert [(t[3]["first_op"] >> (5 * j)) & 31 for j in range(4)] == [1, 2, 2, 3]
+    # a patch in a wall's plane and a rect elsewhere are no faces: they stay, a run split around the walls that left it
+    spec = [("w", YZ, True), ("p", YZ, True), ("w", YZ, False), ("r",), ("r",), ("w", XZ, False), ("w", XY, True)]
+    t = R.debug_objects(_room_list(pbe, spec))
+    assert [(o["geom_count"], bool(o["is_cube"] & 2)) for o in t] == [(1, False), (2, False), (4, True)]
+    assert [(t[2]["first_op"] >> (5 * j)) & 31 for j in range(4)] == [0, 1, 2, 2]
+    # a second wall on a face stays an ordinary rect (searched before the room: it stood before the last wall); a wrapped wall is no wall
+    spec = [("w", YZ, True), ("w", YZ, True), ("w", YZ, False), ("f", ("w", XZ, True)), ("w", XZ, False), ("w", XY, True)]
+    t = R.debug_objects(_room_list(pbe, spec))
+    assert [(o["geom_count"], o["n_ops"], bool(o["is_cube"] & 2)) for o in t] == [(1, 0, False), (1, 1, False), (4, 0, True)]
+    assert [(t[2]["first_op"] >> (5 * j)) & 31 for j in range(4)] == [0, 1, 2, 2]
+    # scenes the list-scene kernels do not serve keep their lists (a sphere: F_SPHERES)
+    b = _room_list(pbe, [("w", XY, True), ("w", XZ, True), ("w", YZ, True), ("w", YZ, False)])
+    b2 = SceneBuilder(pbe)
+    m = b2.Lambertian(b2.ConstantTexture((0.5, 0.5, 0.5)))
+    w = b2.HittableList()
+    for pl, k in ((XY, 8.0), (XY, 0.0)):
+        w.push(b2.AARect(pl, 0.0, 4.0, 0.0, 6.0, k, m))
+    for pl, k in ((XZ, 6.0), (XZ, 0.0)):
+        w.push(b2.AARect(pl, 0.0, 4.0, 0.0, 8.0, k, m))
+    w.push(b2.Sphere((2.0, 2.0, 2.0), 1.0, m))
+    b2.set_scene(w, [])
+    assert rooms(b2) == [] and len(rooms(b)) == 1
 
 
 def test_flatten_duplicated_handle_in_a_list(pbe):
