@@ -309,6 +309,10 @@ int rt_debug_aabb_hit(uint32_t n, const double* boxes, const double* rays, const
  * -1), t of the fast path (rt_kernel.hip: cube_fast; NaN: no hit), 8 * clear + (face + 1) of the fast path (clear:
  * the lane's outcome is outside the approximation's margin — otherwise the kernels run the six tests).  Non-zero on a HIP error. */
 int rt_debug_cube_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, double* out);
+/* The same for the fast path's ROOM form (round 6: walls of a list scene that are faces of one box, rt_flatten.cpp form_room): masks[i]
+ * says which of the six faces exist (bit f = face f in cube.rs:17-24 order); the exact side is HittableList::hit (hit.rs:59-71) over
+ * the AARects of those faces.  out as above. */
+int rt_debug_room_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, const uint32_t* masks, double* out);
 /* Debugging aid for parity work: the hits of ONE camera path, level by level.  rt_debug_trace_path chooses the path (local pixel index =
  * output-order pixel for an unsharded render, sample index; -1 switches it off); the following renders record, per level of ray_color
  * that found a hit, 16 doubles at out[16 * level]: t, position[3], normal[3], front_face, object, primitive kind, primitive index,

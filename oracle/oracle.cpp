@@ -1412,6 +1412,29 @@ void orc_cube_hit_batch(uint32_t n, const double* boxes, const double* rays, con
         out[2 * i + 1] = (double)face;
     }
 }
+// The same for a ROOM: HittableList::hit (hit.rs:59-71) over those of the six faces' AARects (rect.rs:49-81) whose bit is set in masks[i]
+// (bit f = the face with index f in cube.rs:17-24 order), in that order — the oracle side of the product's known-answer test of the
+// Cube fast path's room form (rt_debug_room_hit).  out as above.
+void orc_room_hit_batch(uint32_t n, const double* boxes, const double* rays, const double* tlim, const uint32_t* masks, double* out) {
+    Sampler tmp; tmp.rng = Rng::for_stream(0, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        const Cube c(V(boxes + 6 * i), V(boxes + 6 * i + 3), nullptr);
+        HittableList walls; std::vector<int> face_of;
+        int k = 0;
+        for (const Hittable* side : c.sides.list) { if ((masks[i] >> k) & 1u) { walls.push(side); face_of.push_back(k); } k++; }
+        const Ray r(V(rays + 6 * i), V(rays + 6 * i + 3), 0.0);
+        HitRecord rec;
+        const bool any = walls.hit(r, tlim[2 * i], tlim[2 * i + 1], tmp, rec);
+        int face = -1;
+        if (any) {
+            double closest = tlim[2 * i + 1]; HitRecord t2; size_t j = 0;
+            for (const Hittable* side : walls.list) { if (side->hit(r, tlim[2 * i], closest, tmp, t2)) { closest = t2.t; face = face_of[j]; } j++; }
+            if (!(closest == rec.t) && !(closest != closest && rec.t != rec.t)) face = -2;
+        }
+        out[2 * i] = any ? rec.t : double(std::nan(""));
+        out[2 * i + 1] = (double)face;
+    }
+}
 // what built this library (bench.py's cpu_baseline reports it instead of a sentence)
 const char* orc_build_info() {
     return "g++ " __VERSION__

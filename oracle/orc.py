@@ -101,6 +101,8 @@ def _declare(lib) -> Backend:
     lib.orc_build_info.restype = C.c_char_p
     lib.orc_cube_hit_batch.restype = None
     lib.orc_cube_hit_batch.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.orc_room_hit_batch.restype = None
+    lib.orc_room_hit_batch.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     d3 = c_double_p
     lib.orc_sphere_uv.argtypes = [d3, d3]
     lib.orc_reflect.argtypes = [d3, d3, d3]

@@ -2302,6 +2302,45 @@ __global__ void cube_kat_kernel(uint32_t n, float rect_m, const double* boxes, c
     out[i * 4] = t_ref; out[i * 4 + 1] = (double)face_ref; out[i * 4 + 2] = t_fast; out[i * 4 + 3] = (double)((clear ? 8 : 0) + (int)(face + 1u));
 }
 }
+// The same for the ROOM form: masks[i] says which of the six faces exist (bit f = face f in cube.rs:17-24 order); the reference side is
+// HittableList::hit over the rects of those faces, the fast side cube_fast with a face map (a face's place in the map = its own index).
+namespace rt {
+__global__ void room_kat_kernel(uint32_t n, float rect_m, const double* boxes, const double* rays, const double* tlim, const uint32_t* masks, double* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    struct { double mnx, mny, mnz, mxx, mxy, mxz; } b; b.mnx = boxes[i * 6]; b.mny = boxes[i * 6 + 1]; b.mnz = boxes[i * 6 + 2]; b.mxx = boxes[i * 6 + 3]; b.mxy = boxes[i * 6 + 4]; b.mxz = boxes[i * 6 + 5];
+    RayT<double> ray; ray.o = mk<double>(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]); ray.d = mk<double>(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]); ray.tm = 0.0;
+    const double t_min = tlim[i * 2], t_max = tlim[i * 2 + 1];
+    const uint32_t mask = masks[i] & 0x3Fu;
+    DRect<double> f[6] = {{b.mnx, b.mxx, b.mny, b.mxy, b.mxz, 0u, 0u}, {b.mnx, b.mxx, b.mny, b.mxy, b.mnz, 0u, 0u}, {b.mnx, b.mxx, b.mnz, b.mxz, b.mxy, 1u, 0u},
+                          {b.mnx, b.mxx, b.mnz, b.mxz, b.mny, 1u, 0u}, {b.mny, b.mxy, b.mnz, b.mxz, b.mxx, 2u, 0u}, {b.mny, b.mxy, b.mnz, b.mxz, b.mnx, 2u, 0u}};
+    double closest = t_max, t_ref = __builtin_nan(""); int face_ref = -1;
+    uint32_t map = 0u;
+    for (int k = 0; k < 6; k++) {
+        const bool has = ((mask >> k) & 1u) != 0u;
+        map |= (has ? (uint32_t)k : 7u) << (3 * k);
+        double t; if (has && rect_test(f[k], ray, t_min, closest, t)) { closest = t; t_ref = t; face_ref = k; }
+    }
+    map |= 1u << 18;        // (never 0: a Cube with all six faces is a valid room too — the word the flattener makes has its flag bits above the map as well)
+    double t_fast = __builtin_nan(""); uint32_t face = 0xFFFFFFFFu; bool hit = false, clear = false;
+    { double t; uint32_t fc = 0u; (void)cube_fast<false>(rect_m, b.mnx, b.mxx, b.mny, b.mxy, b.mnz, b.mxz, ray, t_min, t_max, t, fc, hit, clear, map); if (hit) { t_fast = t; face = fc; } }
+    out[i * 4] = t_ref; out[i * 4 + 1] = (double)face_ref; out[i * 4 + 2] = t_fast; out[i * 4 + 3] = (double)((clear ? 8 : 0) + (int)(face + 1u));
+}
+}
+extern "C" int rt_debug_room_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, const uint32_t* masks, double* out) {
+    if (n == 0) return 0;
+    double *db = nullptr, *dr = nullptr, *dt = nullptr, *dout = nullptr; uint32_t* dm = nullptr;
+    int rc = -1;
+    if (hipMalloc(&db, n * 48ull) == hipSuccess && hipMalloc(&dr, n * 48ull) == hipSuccess && hipMalloc(&dt, n * 16ull) == hipSuccess &&
+        hipMalloc(&dout, n * 32ull) == hipSuccess && hipMalloc(&dm, n * 4ull) == hipSuccess &&
+        hipMemcpy(db, boxes, n * 48ull, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dr, rays, n * 48ull, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(dt, tlim, n * 16ull, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dm, masks, n * 4ull, hipMemcpyHostToDevice) == hipSuccess) {
+        hipLaunchKernelGGL(rt::room_kat_kernel, dim3((n + 255u) / 256u), dim3(256), 0, nullptr, n, (float)rect_m, db, dr, dt, dm, dout);
+        if (hipGetLastError() == hipSuccess && hipMemcpy(out, dout, n * 32ull, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    }
+    (void)hipFree(db); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dout); (void)hipFree(dm);
+    return rc;
+}
 extern "C" int rt_debug_cube_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, double* out) {
     if (n == 0) return 0;
     double *db = nullptr, *dr = nullptr, *dt = nullptr, *dout = nullptr;

@@ -977,16 +977,8 @@ def test_box_filter_is_conservative_on_grazing_rays(pbe):
     assert not culled32.any(), f"the f32 kernels' filter culled {int(culled32.sum())} boxes their exact test passes, e.g. case {int(np.flatnonzero(culled32)[0])}"
 
 
-def test_cube_fast_path_against_the_six_rect_tests(pbe, obe):
-    """Cube::hit on the device two ways (rt_debug_cube_hit): the reference's six AARect tests in cube.rs:17-24 order under HittableList::hit,
-    and the kernels' fast path (rt_kernel.hip: cube_fast — six approximate plane distances, ONE exact rect test for the face that wins).
-    Wherever the fast path declares a case CLEAR its answer must be the six tests' answer bit for bit: the same t, the same face, or
-    no hit.  Cases aimed at where it could go wrong: rays through points on faces, edges and corners moved by 1e-15 ... 1e-3 of the
-    cube, origins on a face (every bounce off a cube), inside the cube, far away; thin and tiny cubes; cubes far from the origin;
-    [t_min, t_max] ending within ulps of a hit; axis-parallel rays (zero direction components: never clear)."""
-    import ctypes as C
-    rnd = np.random.default_rng(23)
-    n = 600000
+def _cube_kat_cases(rnd, n):
+    """The hostile cases of the Cube known-answer tests: (boxes n x 6, rays n x 6, [t_min, t_max] n x 2, and which cases are of which kind)."""
     scale = 10.0 ** rnd.uniform(-1, 4, (n, 1))
     lo = rnd.uniform(-1, 1, (n, 3)) * scale * rnd.choice([0.0, 1.0, 30.0], (n, 1), p=[0.2, 0.6, 0.2])
     ext = rnd.uniform(0.05, 1, (n, 3)) * scale
@@ -1020,6 +1012,21 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe, obe):
     tmin = np.where(rnd.integers(0, 4, n) == 0, t_hit * (1.0 + rnd.choice([-4, -1, 0, 1, 4], n) * 2.0 ** -52), 1e-5)
     tl = np.stack([tmin, tmax], axis=1)
     rays = np.concatenate([o, d], axis=1)
+    return boxes, rays, tl, dict(kind=kind, axis_par=axis_par, tiny=tiny, thin=thin, tmax=tmax, tmin=tmin)
+
+
+def test_cube_fast_path_against_the_six_rect_tests(pbe, obe):
+    """Cube::hit on the device two ways (rt_debug_cube_hit): the reference's six AARect tests in cube.rs:17-24 order under HittableList::hit,
+    and the kernels' fast path (rt_kernel.hip: cube_fast — six approximate plane distances, ONE exact rect test for the face that wins).
+    Wherever the fast path declares a case CLEAR its answer must be the six tests' answer bit for bit: the same t, the same face, or
+    no hit.  Cases aimed at where it could go wrong: rays through points on faces, edges and corners moved by 1e-15 ... 1e-3 of the
+    cube, origins on a face (every bounce off a cube), inside the cube, far away; thin and tiny cubes; cubes far from the origin;
+    [t_min, t_max] ending within ulps of a hit; axis-parallel rays (zero direction components: never clear)."""
+    import ctypes as C
+    rnd = np.random.default_rng(23)
+    n = 600000
+    boxes, rays, tl, about = _cube_kat_cases(rnd, n)
+    kind, axis_par, tiny, thin, tmax, tmin = (about[k] for k in ("kind", "axis_par", "tiny", "thin", "tmax", "tmin"))
     out = np.zeros((n, 4))
     lib = pbe.lib
     lib.rt_debug_cube_hit.restype = C.c_int
@@ -1053,6 +1060,66 @@ def test_cube_fast_path_against_the_six_rect_tests(pbe, obe):
     assert not bad2.any()
     # plain rays are (nearly) always clear: the fast path is what runs
     plain = (kind == 4) & ~axis_par & ~tiny & ~thin & (np.isinf(tmax)) & (tmin == 1e-5)   # a random direction from a random origin
+    assert clear[plain].mean() > 0.99, clear[plain].mean()
+
+
+def test_room_form_of_the_cube_fast_path_against_the_walls_rect_tests(pbe, obe):
+    """The fast path's ROOM form (round 6: walls of a list scene that are faces of one box, rt_flatten.cpp form_room — the Cornell room's five
+    walls): the same hostile cases as the Cube test, each with a random set of faces that exist (every set of 0 ... 6).  Wherever the fast
+    path declares a case CLEAR its answer must be HittableList::hit's over the rects of the faces that exist, bit for bit — the entry face
+    if it exists and is in range, else the exit face if it exists and is in range, else no hit — and the device's exact side IS the
+    oracle's list over those AARects (orc_room_hit_batch) on every case.  With all six faces the room form must say what the Cube form says."""
+    import ctypes as C
+    rnd = np.random.default_rng(29)
+    n = 600000
+    boxes, rays, tl, about = _cube_kat_cases(rnd, n)
+    masks = rnd.integers(0, 64, n).astype(np.uint32)
+    # (bit f = face f of cube.rs:17-24: z max, z min, y max, y min, x max, x min)
+    masks[rnd.integers(0, 5, n) == 0] = 0x3D                                    # the Cornell room of main.rs:291-296: everything but the face at min z, the open front
+    masks[rnd.integers(0, 10, n) == 0] = 0x3E                                   # ... but the one at max z
+    masks[rnd.integers(0, 20, n) == 0] = 0x3F                                   # all six
+    out = np.zeros((n, 4))
+    lib = pbe.lib
+    lib.rt_debug_room_hit.restype = C.c_int
+    lib.rt_debug_room_hit.argtypes = [C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    boxes, rays, tl = (np.ascontiguousarray(x, dtype=np.float64) for x in (boxes, rays, tl))
+    rect_m = float(np.abs(boxes).max()) * 1.0000002
+    assert lib.rt_debug_room_hit(n, rect_m, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, masks.ctypes.data, out.ctypes.data) == 0
+    t_ref, face_ref, t_fast, code = out[:, 0].copy(), out[:, 1].astype(int), out[:, 2].copy(), out[:, 3].astype(int)
+    clear = (code & 8) != 0
+    face_fast = (code & 7) - 1
+    assert clear.sum() > 0.5 * n and (~clear).sum() > 0.02 * n, (int(clear.sum()), n)
+    hit_ref = ~np.isnan(t_ref)
+    assert 0.05 * n < hit_ref.sum() < 0.9 * n
+    assert not clear[about["axis_par"]].any()
+    assert (((masks[hit_ref] >> face_ref[hit_ref]) & 1) == 1).all(), "a face that does not exist was hit"
+    bad = clear & ((face_fast != face_ref) | (t_fast.view(np.uint64) != t_ref.view(np.uint64)) & ~(np.isnan(t_fast) & np.isnan(t_ref)))
+    assert not bad.any(), f"{int(bad.sum())} clear cases differ from the walls' rect tests, e.g. case {int(np.flatnonzero(bad)[0])}: mask {int(masks[np.flatnonzero(bad)[0]]):06b} " \
+                          f"ref (t {t_ref[np.flatnonzero(bad)[0]]!r}, face {face_ref[np.flatnonzero(bad)[0]]}) fast (t {t_fast[np.flatnonzero(bad)[0]]!r}, face {face_fast[np.flatnonzero(bad)[0]]})"
+    # the device's exact side is the oracle's HittableList over the AARects of the faces that exist
+    ref2 = np.zeros((n, 2))
+    obe.lib.orc_room_hit_batch(n, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, masks.ctypes.data, ref2.ctypes.data)
+    t_orc, face_orc = ref2[:, 0], ref2[:, 1].astype(int)
+    assert (face_orc >= -1).all()
+    differ = (face_orc != face_ref) | ((t_orc.view(np.uint64) != t_ref.view(np.uint64)) & ~(np.isnan(t_orc) & np.isnan(t_ref)))
+    assert not differ.any(), f"{int(differ.sum())} cases: the device's wall tests differ from the oracle's list, e.g. case {int(np.flatnonzero(differ)[0])}"
+    # an absent face matters: among the clear cases some hit the exit face BECAUSE the entry face does not exist, some nothing at all
+    full = np.zeros((n, 4))
+    lib.rt_debug_cube_hit.restype = C.c_int
+    lib.rt_debug_cube_hit.argtypes = [C.c_uint32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    assert lib.rt_debug_cube_hit(n, rect_m, boxes.ctypes.data, rays.ctypes.data, tl.ctypes.data, full.ctypes.data) == 0
+    cube_face = (full[:, 3].astype(int) & 7) - 1
+    cube_clear = (full[:, 3].astype(int) & 8) != 0
+    both = clear & cube_clear
+    assert (both & (cube_face >= 0) & (face_fast >= 0) & (cube_face != face_fast)).sum() > 1000, "no case where the exit face stands in for an absent entry face"
+    assert (both & (cube_face >= 0) & (face_fast < 0)).sum() > 1000
+    # every face there: the room form is the Cube form
+    six = masks == 0x3F
+    assert six.sum() > 5000
+    same = (code[six] == full[six, 3].astype(int)) & ((t_fast[six].view(np.uint64) == full[six, 2].view(np.uint64)) | (np.isnan(t_fast[six]) & np.isnan(full[six, 2])))
+    assert same.all()
+    # plain rays are (nearly) always clear with any set of faces
+    plain = (about["kind"] == 4) & ~about["axis_par"] & ~about["tiny"] & ~about["thin"] & np.isinf(about["tmax"]) & (about["tmin"] == 1e-5)
     assert clear[plain].mean() > 0.99, clear[plain].mean()
 
 
