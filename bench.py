@@ -199,9 +199,13 @@ def roofline_of(w, local_samples, k_ms, n_flush, kernel_name, with_pmc, instanti
             if waves and all(k in vals for k in need) and vals["SQ_WAVE_CYCLES"] > 0 and vals["SQ_ACTIVE_INST_VALU"] > 0:
                 # SQ_ACTIVE_INST_VALU and SQ_WAVE_CYCLES count quad-cycles summed over waves; the grid is persistent, so
                 # SQ_WAVE_CYCLES / waves is the launch's length in quad-cycles and waves / 1024 the waves per SIMD.
-                busy = vals["SQ_ACTIVE_INST_VALU"] * (waves / N_SIMD) / vals["SQ_WAVE_CYCLES"]
+                # (a SIMD that issues vector instructions back to back reads slightly ABOVE 1 here — C2 / C5 1.05 since the room form put f32
+                # instructions where f64 divisions were: the counter tallies, per wave, the quad-cycles a vector instruction is in flight, and
+                # consecutive instructions of different waves overlap by a pipeline stage.  The line keeps the raw value and uses min(1, raw).)
+                busy_raw = vals["SQ_ACTIVE_INST_VALU"] * (waves / N_SIMD) / vals["SQ_WAVE_CYCLES"]
+                busy = min(1.0, busy_raw)
                 lanes = vals["SQ_THREAD_CYCLES_VALU"] / (64.0 * vals["SQ_ACTIVE_INST_VALU"])
-                valu = {"valu_busy_frac": busy, "valu_lane_utilisation": lanes, "frac": busy * lanes,
+                valu = {"valu_busy_frac": busy, "valu_busy_frac_raw": busy_raw, "valu_lane_utilisation": lanes, "frac": busy * lanes,
                         "frac_meaning": "useful VALU lane-slots (every VALU instruction, not only f64 arithmetic) / lane-slots the SIMDs could have issued over the launch",
                         "source": f"profiles/{src}: committed rocprofv3 --pmc passes of this command on this build (not measured in this run)"}
                 roof["executed_valu_frac"] = valu["frac"]
