@@ -313,6 +313,12 @@ int rt_debug_cube_hit(uint32_t n, double rect_m, const double* boxes, const doub
  * says which of the six faces exist (bit f = face f in cube.rs:17-24 order); the exact side is HittableList::hit (hit.rs:59-71) over
  * the AARects of those faces.  out as above. */
 int rt_debug_room_hit(uint32_t n, double rect_m, const double* boxes, const double* rays, const double* tlim, const uint32_t* masks, double* out);
+/* Known-answer access to the closest-hit search of a LIST scene (no feature bit: what the lean kernels serve — rects, Cubes, wrapped ones):
+ * world.hit (main.rs:48, HittableList::hit hit.rs:59-71) and the hit record for n given rays through the kernels' own search.  rays: n x
+ * (origin[3], direction[3]); t_min: n; out: n x 12 = hit (0 / 1), t, position[3], normal[3], front_face, object index, primitive index,
+ * material.  Host pointers.  What the room form's order argument rests on is tested through this: rays that start ON planes, with zero
+ * direction components (0 / 0 plane distances), non-finite rays. */
+int rt_debug_list_hit(rt_scene*, uint32_t n, const double* rays, const double* t_min, double* out);
 /* Debugging aid for parity work: the hits of ONE camera path, level by level.  rt_debug_trace_path chooses the path (local pixel index =
  * output-order pixel for an unsharded render, sample index; -1 switches it off); the following renders record, per level of ray_color
  * that found a hit, 16 doubles at out[16 * level]: t, position[3], normal[3], front_face, object, primitive kind, primitive index,

@@ -477,6 +477,17 @@ struct Flattener {
             else { DObject o = f.objects[it.obj]; o.geom_first = (uint32_t)it.rect; o.geom_count = 1u; new_of[x] = (uint32_t)out.size(); out.push_back(o); }
         }
         if (room_at > 31u) return;
+        // What stands between the first and the last wall is searched BEFORE walls it stood behind.  That is the same search as long as
+        // every plane distance is a number (the argument above); a NaN one — 0 / 0: a ray with a zero direction component that starts ON
+        // a plane — is accepted by `t < t_min || t > t_max` and makes every later item pass `t <= closest`, i.e. the result then depends
+        // on the ORDER.  The kernel sends every wave that holds a ray with a zero or non-finite direction component through the list as
+        // the reference has it (n_alt, below; rt_kernel.hip world_hit_list); for that test to cover the objects in between they must
+        // see the path's own ray: no Translate / Rotate among them (FlipNormals change the record only).
+        for (size_t x = best.front() + 1u; x < last; x++) {
+            if (is_wall[x]) continue;
+            const DObject& o = f.objects[items[x].obj];
+            if (o.n_ops != 0u && !(o.nest & 0x10000u)) return;
+        }
         DObject room{};
         room.geom_kind = G_RECT; room.geom_first = (uint32_t)f.rects.size(); room.geom_count = (uint32_t)best.size();
         room.first_op = 0u; room.n_ops = 0u; room.medium = -1; room.nest = 0u;
@@ -494,8 +505,14 @@ struct Flattener {
         f.rects.push_back({bmn[0], bmx[0], bmn[1], bmx[1], bmx[2], 0u, mat0});       // the box, laid out like a Cube's first two faces (never tested, never hit)
         f.rects.push_back({bmn[0], bmx[0], bmn[1], bmx[1], bmn[2], 0u, mat0});
         out[room_at] = room;
+        // the list as the reference has it stays behind the new one: what a wave searches when a ray of it could produce a NaN plane
+        // distance (rt_kernel.hip: world_hit)
+        room_n_top = (uint32_t)out.size();
+        f.n_alt = n;
+        out.insert(out.end(), f.objects.begin(), f.objects.end());
         f.objects.swap(out);
     }
+    uint32_t room_n_top = 0;               // != 0: form_room made a room; the world list is objects[0, room_n_top)
 
     bool run() {
         f = HostFlat{};
@@ -514,7 +531,7 @@ struct Flattener {
         if (!emit(s.world, c, -1)) return false;
         form_room();
         // the sub-objects follow the world's own objects in the one table: G_OBJ leaves learn their final indices
-        f.n_top = (uint32_t)f.objects.size();
+        f.n_top = room_n_top ? room_n_top : (uint32_t)f.objects.size();
         if (!subs.empty()) {
             for (DBvhNode<double>& nd : f.bvh)
                 if ((nd.a & BVH_LEAF) && ((nd.a >> 28) & 7u) == G_OBJ) {

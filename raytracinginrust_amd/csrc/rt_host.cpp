@@ -611,6 +611,10 @@ template <typename T> uint32_t cached_nodes(const LaunchShape& g, const HostFlat
     return (uint32_t)std::min(room, f.bvh.size());
 }
 
+// RT_ROOM_NO_NAN_PATH (tests only): the kernels never leave the list with the room for the list as the reference has it — what
+// tests/test_fuzz_gpu.py uses to show that its hostile rays do find the order-dependent NaN hits that path exists for.
+static bool room_nan_path() { return std::getenv("RT_ROOM_NO_NAN_PATH") == nullptr; }
+
 template <typename T>
 int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
                 uint64_t seed, uint32_t flags, uint32_t tile_px, uint32_t rank, uint32_t world, void* d_out, size_t d_out_bytes,
@@ -623,7 +627,7 @@ int render_impl(Scene& s, const rt_camera* camp, const double bg[3], uint32_t W,
     const HostFlat& f = s.flat;
     KParams<T> P;
     std::memset((void*)&P, 0, sizeof(P));
-    P.objects = (const DObject*)d.objects; P.n_objects = f.n_top;
+    P.objects = (const DObject*)d.objects; P.n_objects = f.n_top; P.n_objects_alt = room_nan_path() ? f.n_alt : 0u;
     P.ops = (const DOp<T>*)d.ops; P.rects = (const DRect<T>*)d.rects; P.spheres = (const DSphere<T>*)d.spheres;
     P.mspheres = (const DMSphere<T>*)d.mspheres; P.tris = (const DTri<T>*)d.tris; P.bvh = (const DBvhNode<T>*)d.bvh;
     P.n_bvh = (uint32_t)f.bvh.size();
@@ -1014,6 +1018,33 @@ int rt_debug_section_cycles(rt_scene* sc, unsigned long long out[8]) {
 }
 
 // Debugging aid (see include/rt_amd.h): choose the path whose hits the next renders record / fetch the record
+// Known-answer access to the closest-hit search of a LIST scene (no feature bit set: what the lean kernels serve): world.hit (main.rs:48)
+// and the hit record for n given rays, through the kernels' own world_hit / finalize_hit.  rays: n x (origin[3], direction[3]); t_min: n;
+// out: n x 12 = hit, t, position[3], normal[3], front_face, object index, primitive index, material.  Host pointers.
+int rt_debug_list_hit(rt_scene* sc, uint32_t n, const double* rays, const double* t_min, double* out) {
+    if (!sc || !rays || !t_min || !out) return set_err("null argument");
+    if (n == 0) return 0;
+    Scene& s = sc->s;
+    if (!flatten_scene(s)) { g_err = s.error; return -1; }
+    if (s.flat.feats != 0u) return set_err("rt_debug_list_hit serves list scenes only (no BVH, sphere, triangle, medium, texture, dielectric or PBR)");
+    Scene::DeviceCtx* cp = nullptr;
+    if (current_ctx(s, &cp)) return -1;
+    DeviceScene<double>& d = dev_of<double>(*cp);
+    if (ensure_uploaded<double>(s, d)) return -1;
+    const HostFlat& f = s.flat;
+    KParams<double> P;
+    std::memset((void*)&P, 0, sizeof(P));
+    P.objects = (const DObject*)d.objects; P.n_objects = f.n_top; P.n_objects_alt = room_nan_path() ? f.n_alt : 0u;
+    P.ops = (const DOp<double>*)d.ops; P.rects = (const DRect<double>*)d.rects; P.rect_m = f.rect_m;
+    P.materials = (const DMaterial<double>*)d.materials; P.textures = (const DTexture<double>*)d.textures;
+    double *dr = nullptr, *dt = nullptr, *dout = nullptr;
+    int rc = -1;
+    if (hipMalloc(&dr, n * 48ull) == hipSuccess && hipMalloc(&dt, n * 8ull) == hipSuccess && hipMalloc(&dout, n * 96ull) == hipSuccess &&
+        hipMemcpy(dr, rays, n * 48ull, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(dt, t_min, n * 8ull, hipMemcpyHostToDevice) == hipSuccess &&
+        launch_list_hit_kat(P, n, dr, dt, dout, nullptr) == hipSuccess && hipMemcpy(out, dout, n * 96ull, hipMemcpyDeviceToHost) == hipSuccess) rc = 0;
+    (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dout);
+    return rc == 0 ? 0 : set_err("rt_debug_list_hit: a HIP call failed");
+}
 int rt_debug_trace_path(rt_scene* sc, long long local_pixel, long long sample) {
     if (!sc) return set_err("null argument");
     sc->s.trace_px = local_pixel; sc->s.trace_s = sample;

@@ -137,6 +137,11 @@ template <typename T> struct KParams {
     // Cube fast path (rt_kernel.hip: cube_hit): >= every |coordinate| of every rect; 0 = off (a Cube with min > max on some axis, or a
     // non-finite coordinate: the six exact tests then)
     float rect_m;
+    // Room form (list scenes; rt_flatten.cpp form_room): objects[n_objects, n_objects + n_objects_alt) is the world list AS THE REFERENCE HAS
+    // IT, behind the list with the room.  A wave in which some lane's ray has a zero or non-finite component — the only rays for which a
+    // plane distance can be NaN, and a NaN hit makes HittableList::hit depend on the order of the items — searches that list instead
+    // (rt_kernel.hip: world_hit_list).  0: none.
+    uint32_t n_objects_alt;
 };
 
 } // namespace rt

@@ -872,6 +872,8 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
             // walls is searched before all of them.  HittableList::hit's result is the hit with the smallest t, the LATER item on an exact
             // tie (hit.rs:62-68: `t <= closest` accepts); every t is compared as before, only a tie between a wall and an object that came
             // AFTER it in the list must still go to that object: first_op holds, five bits per wall, the index of the first such object.
+            // (All of which is about plane distances that are numbers: a wave with a ray that could make a NaN one searches the list as
+            // the reference has it instead — world_hit.)
             bool keep = true;
             if (ob.is_cube & 2u) keep = !(any && t == closest && id.obj >= ((ob.first_op >> (5u * ((prim & 0x0FFFFFFFu) - ob.geom_first))) & 31u));
             if (keep) { closest = t; id.obj = oi; id.prim = prim; any = true; }
@@ -902,6 +904,36 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
             }
         }
     }
+}
+
+// world.hit of a LIST scene (the lean kernels, FEATS 0).  With a room in the list (rt_flatten.cpp form_room) the list [0, n_objects) searches
+// things that stood between two walls before walls they stood behind — the same search whenever every plane distance is a number.  A NaN one
+// (0 / 0: a zero direction component on a ray that starts ON a plane; or a ray that is not finite) passes `t < t_min || t > t_max` and
+// then lets every later item pass `t <= closest`: HittableList::hit's result then depends on the ORDER of the items (hit.rs:59-71).
+// Everything between the first and the last wall sees the path's own ray (the flattener's condition), so a plane distance (k - o_k) / d_k
+// can only be NaN when a direction component is a zero or the ray is not finite.  So, BEFORE the search: a wave in which some lane's
+// direction has a zero, denormal or non-finite component, or a non-finite origin, searches objects[n_objects, n_objects + n_objects_alt)
+// — the list as the reference has it — instead.  Six v_cmp_class_f64 per bounce (*measured*, profiles/r06_room_ab.log: the room form
+// +2.3 % without this, +1.6 % with it; testing the origins only in waves that have met such a ray before — a wave flag kept scalar by
+// readfirstlane — is no faster and needs an argument about origins; a re-search after the room has found such a lane costs all of the
+// gain: the outer loop spills thirteen more scalar registers).  Objects before the first and after the last wall are searched in the
+// same order by both lists, so whatever THEY return — NaN hits of rotated boxes included — is the reference's either way.
+template <typename T> DEV bool risky_component(T x, bool origin);
+template <> DEV bool risky_component<double>(double x, bool origin) { return origin ? __builtin_amdgcn_class(x, 0x207) : __builtin_amdgcn_class(x, 0x2F7); }     // NaN, inf (| zero, denormal)
+template <> DEV bool risky_component<float>(float x, bool origin) { return origin ? __builtin_amdgcn_classf(x, 0x207) : __builtin_amdgcn_classf(x, 0x2F7); }
+template <typename T>
+DEV bool world_hit_list(const KParams<T>& P, const RayT<T>& ray, T t_min, Rng& rng, T& t_hit, HitId& id) {
+    T closest = Lim<T>::inf();
+    bool any = false;
+    uint32_t oi = 0u, oi_last = P.n_objects;
+    if (P.n_objects_alt != 0u) {
+        const bool risk = risky_component(ray.d.x, false) || risky_component(ray.d.y, false) || risky_component(ray.d.z, false) ||
+                          risky_component(ray.o.x, true) || risky_component(ray.o.y, true) || risky_component(ray.o.z, true);
+        if (__ballot(risk) != 0ull) { oi = oi_last; oi_last += P.n_objects_alt; }
+    }
+    for (; oi < oi_last; oi++) object_hit<T, 0u>(P, oi, ld_obj(P.objects + oi), ray, t_min, rng, closest, id, any, nullptr);      // wave-uniform: scalar loads
+    t_hit = closest;
+    return any;
 }
 
 template <typename T, uint32_t FEATS>
@@ -1799,7 +1831,9 @@ DEV void trace_lockstep(const KParams<T>& P, uint32_t lane, T* q_real, uint32_t*
                 done = true;                            // main.rs:42-45
             } else {
                 T t_hit; HitId id; id.obj = 0; id.prim = 0;
-                const bool any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);   // main.rs:48
+                bool any_hit;                                                                            // main.rs:48
+                if constexpr (FEATS == 0u) any_hit = world_hit_list<T>(P, ray, TMin<T>::v(), rng, t_hit, id);
+                else any_hit = world_hit<T, FEATS>(P, ray, TMin<T>::v(), rng, t_hit, id, stack);
                 DIAG_ADD(2);
                 if (!any_hit) {
                     e = ld3(P.background); done = true;                                     // main.rs:118
@@ -2177,6 +2211,28 @@ template hipError_t launch_lean<double>(const KParams<double>&, uint32_t, size_t
 template hipError_t launch_lean<float>(const KParams<float>&, uint32_t, size_t, hipStream_t);
 template int occupancy_lean<double>(size_t);
 template int occupancy_lean<float>(size_t);
+// Known-answer access to the list-scene kernels' closest-hit search (rt_debug_list_hit): world.hit (main.rs:48) + the hit record for
+// given rays — world_hit<double, 0> and finalize_hit<double, 0>, the code the frames run, one ray per lane, waves of 64 (the search
+// votes).  out[12 i ..] = hit (0 / 1), t, position[3], normal[3], front_face, object, primitive, material.
+__global__ void list_hit_kat_kernel(const KParams<double> P, uint32_t n, const double* rays, const double* tlim, double* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t j = i < n ? i : n - 1u;                           // (a partial last wave repeats the last ray: every lane takes part in the votes)
+    RayT<double> ray; ray.o = mk<double>(rays[j * 6], rays[j * 6 + 1], rays[j * 6 + 2]); ray.d = mk<double>(rays[j * 6 + 3], rays[j * 6 + 4], rays[j * 6 + 5]); ray.tm = 0.0;
+    Rng rng = rng_for_path(0ull, 0u, 0u);
+    double t_hit; HitId id; id.obj = 0u; id.prim = 0u;
+    const bool any = world_hit_list<double>(P, ray, tlim[j], rng, t_hit, id);
+    Rec<double> rec; rec.p = mk<double>(0.0, 0.0, 0.0); rec.n = rec.p; rec.t = 0.0; rec.u = rec.v = 0.0; rec.front = false; rec.mat = 0u;
+    if (any) finalize_hit<double, 0u>(P, ray, t_hit, id, true, rec);
+    if (i < n) {
+        double* o = out + 12ull * i;
+        o[0] = any ? 1.0 : 0.0; o[1] = any ? rec.t : 0.0; o[2] = rec.p.x; o[3] = rec.p.y; o[4] = rec.p.z; o[5] = rec.n.x; o[6] = rec.n.y; o[7] = rec.n.z;
+        o[8] = rec.front ? 1.0 : 0.0; o[9] = any ? (double)id.obj : -1.0; o[10] = any ? (double)(id.prim & 0x0FFFFFFFu) : -1.0; o[11] = any ? (double)rec.mat : -1.0;
+    }
+}
+hipError_t launch_list_hit_kat(const KParams<double>& P, uint32_t n, const double* d_rays, const double* d_tlim, double* d_out, hipStream_t stream) {
+    hipLaunchKernelGGL(list_hit_kat_kernel, dim3((n + 63u) / 64u), dim3(64), 0, stream, P, n, d_rays, d_tlim, d_out);
+    return hipGetLastError();
+}
 #endif
 
 #if defined(RT_KRES_ONLY)      // tools/kres.py: one instantiation only (compile-time exploration, never the product build)

@@ -22,6 +22,8 @@ static const uint32_t RT_STATS_SLOTS = 16u, RT_STATS_ROWS = 32u;
 static const size_t RT_STATS_BYTES = (size_t)RT_STATS_SLOTS * RT_STATS_ROWS * sizeof(unsigned long long);
 // Launch the persistent path-tracing kernel: n_blocks workgroups of pathtrace_shape().threads threads, `shmem` bytes of dynamic LDS (above).
 template <typename T> hipError_t launch_pathtrace(const KParams<T>& P, uint32_t scene_feats, uint32_t n_blocks, size_t shmem, hipStream_t stream);
+// Known-answer access to the list-scene kernels' closest-hit search (rt_debug_list_hit; the kernel lives in the lean translation unit)
+hipError_t launch_list_hit_kat(const KParams<double>& P, uint32_t n, const double* d_rays, const double* d_tlim, double* d_out, hipStream_t stream);
 // Resident blocks per CU for the instantiation that serves `scene_feats`.
 template <typename T> int pathtrace_blocks_per_cu(uint32_t scene_feats, uint32_t flags, size_t shmem);
 }

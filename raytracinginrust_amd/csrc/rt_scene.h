@@ -23,6 +23,7 @@ struct HPerlin { double rd_vec[256 * 3]; uint8_t perm[3][256]; };
 struct HostFlat {             // canonical f64 flattening
     std::vector<DObject> objects;  // the world's top-level objects [0, n_top), then the sub-objects BVH leaves of kind G_OBJ refer to
     uint32_t n_top = 0;
+    uint32_t n_alt = 0;            // list scenes with a room (form_room): objects[n_top, n_top + n_alt) = the world list as the reference has it
     std::vector<DOp<double>> ops;
     std::vector<DRect<double>> rects;
     std::vector<DSphere<double>> spheres;
