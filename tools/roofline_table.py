@@ -12,7 +12,8 @@ for W in ("C1", "C2", "C3", "C4", "C5"):
     kern = pm.get("kernel") or d["roofline"]["kernel"]
     assert "loop" not in d or d["loop"]["kernel"] == kern, (W, d["loop"]["kernel"], kern)
     names = {W: "`" + kern.replace("rt::", "") + "`" + notes.get(W, "")}
-    busy = min(1.0, f("SQ_ACTIVE_INST_VALU") * (f("LAUNCH_WAVES") / 1024) / f("SQ_WAVE_CYCLES")); lanes      # (raw 1.05 on C2 / C5: bench.py says why) = f("SQ_THREAD_CYCLES_VALU") / (64 * f("SQ_ACTIVE_INST_VALU"))
+    busy = min(1.0, f("SQ_ACTIVE_INST_VALU") * (f("LAUNCH_WAVES") / 1024) / f("SQ_WAVE_CYCLES"))      # (raw 1.05 on C2 / C5: bench.py says why)
+    lanes = f("SQ_THREAD_CYCLES_VALU") / (64 * f("SQ_ACTIVE_INST_VALU"))
     fetch, write = f("FETCH_SIZE") * 1024 / 1e9, f("WRITE_SIZE") * 1024 / 1e9
     gbps = (fetch + write) / (r["kernel_ms"] * 1e-3)
     ks = [x for x in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{tag}_bench_{W}_kernel_stats.csv"))) if "pathtrace" in x["Name"]][0]
