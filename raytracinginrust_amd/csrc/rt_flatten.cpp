@@ -416,7 +416,11 @@ struct Flattener {
     //     beyond that index (rt_kernel.hip: object_hit).
     // At least four walls (three exact tests cost what the fast path's approximate phase does); RT_NO_ROOM (A/B runs, tests) turns it off.
     void form_room() {
-        if (f.feats != 0u || !subs.empty() || std::getenv("RT_NO_ROOM")) return;
+        // (list scenes — no feature bit —; and, in the SIMPLE form only — the walls next to each other in the list, nothing between them: the
+        // room then stands exactly where they stood, no order changes, no tie rule, no second list —, scenes whose only other feature is a
+        // BVH of triangles: the mesh kernels carry the fast path at the world list's site, rt_kernel.hip RoomSite; the teapot room, C4)
+        const bool mesh_scene = f.feats != 0u && (f.feats & ~(uint32_t)(F_BVH | F_TRIS)) == 0u;
+        if ((f.feats != 0u && !mesh_scene) || !subs.empty() || std::getenv("RT_NO_ROOM")) return;
         const uint32_t n = (uint32_t)f.objects.size();
         // the list, item by item: a run of bare rects is the rects it holds (HittableList[a, b] is a then b), anything else is itself
         struct Item { uint32_t obj; int rect; };                // rect < 0: the whole object, not a candidate
@@ -477,6 +481,7 @@ struct Flattener {
             else { DObject o = f.objects[it.obj]; o.geom_first = (uint32_t)it.rect; o.geom_count = 1u; new_of[x] = (uint32_t)out.size(); out.push_back(o); }
         }
         if (room_at > 31u) return;
+        if (mesh_scene) for (size_t x = best.front() + 1u; x < last; x++) if (!is_wall[x]) return;
         // What stands between the first and the last wall is searched BEFORE walls it stood behind.  That is the same search as long as
         // every plane distance is a number (the argument above); a NaN one — 0 / 0: a ray with a zero direction component that starts ON
         // a plane — is accepted by `t < t_min || t > t_max` and makes every later item pass `t <= closest`, i.e. the result then depends
@@ -508,8 +513,7 @@ struct Flattener {
         // the list as the reference has it stays behind the new one: what a wave searches when a ray of it could produce a NaN plane
         // distance (rt_kernel.hip: world_hit)
         room_n_top = (uint32_t)out.size();
-        f.n_alt = n;
-        out.insert(out.end(), f.objects.begin(), f.objects.end());
+        if (!mesh_scene) { f.n_alt = n; out.insert(out.end(), f.objects.begin(), f.objects.end()); }
         f.objects.swap(out);
     }
     uint32_t room_n_top = 0;               // != 0: form_room made a room; the world list is objects[0, room_n_top)

@@ -340,7 +340,10 @@ template <typename T> DEV bool tri_test(const DTri<T>& tr, const RayT<T>& ray, T
 // so of the faces that exist the list accepts the entry face if it exists and lies in range, else the exit face if it exists and lies in
 // range, else nothing — an absent face is classed "out of range", whatever its distance.  face_out is then the record's place in the run.
 // map == 0: a Cube, all six faces, face_out in cube.rs order (the code above, unchanged).
-template <bool WAVE>
+// (SITE: which call site family an instantiation serves — 0 everything, 1 the mesh kernels' world list.  The compiler's interprocedural
+// constant propagation folds `map == 0` INTO these functions where every caller of the translation unit passes it; a caller with a real map
+// would undo that for all of them and shift the other kernels' register allocation: its own copy keeps the others' machine code as it was.)
+template <bool WAVE, int SITE = 0>
 DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy, double mnz, double mxz, const RayT<double>& ray, double t_min, double t_max,
                    double& t_out, uint32_t& face_out, bool& any, bool& clear_out, uint32_t map = 0u) {
     const float rx = __builtin_amdgcn_rcpf((float)ray.d.x), ry = __builtin_amdgcn_rcpf((float)ray.d.y), rz = __builtin_amdgcn_rcpf((float)ray.d.z);
@@ -406,12 +409,18 @@ DEV bool cube_fast(float rect_m, double mnx, double mxx, double mny, double mxy,
 template <typename T, uint32_t FEATS> struct CubeFast { static constexpr bool on = sizeof(T) == 8u && ((FEATS & F_BVH) == 0u || ((FEATS & F_SPHERES) != 0u && (FEATS & F_SPEC) == 0u)); };
 // `room` (DObject::is_cube of a room object: 2 | map << 8; 0 for a Cube): the run holds `count` wall records in the list's order and, behind
 // them, two records that only carry the box — laid out like a Cube's first two faces.
+// The mesh kernels (BVH of triangles beside list objects: the teapot room, C4) carry the fast path at ONE site — the world list's objects —
+// for rooms (round 6: their five walls stand next to each other in the list, nothing between them, so the room stands exactly where they
+// stood: no tie rule, no second list) and bare Cubes; their BVH leaves hold triangles and keep the plain code (*measured* round 5: the
+// fast path compiled into the leaf tests costs these kernels 1 % and serves nothing there).
+template <typename T, uint32_t FEATS> struct RoomSite { static constexpr bool on = sizeof(T) == 8u && (FEATS & ~(uint32_t)(F_PERSIST | F_NEAR_FIRST)) == (uint32_t)(F_BVH | F_TRIS); };
+template <int SITE = 0>
 DEV bool cube_hit(const KParams<double>& P, uint32_t first, uint32_t count, uint32_t room, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
     const uint32_t box_at = room != 0u ? first + count : first;
     const DRect<double> f0 = ld_rect(P.rects + box_at);                 // XY face at z = max.z: a = x range, b = y range (cube.rs:17)
     const double mnz = cl(&P.rects[box_at + 1u].k);                     // XY face at z = min.z (cube.rs:18)
     uint32_t face = 0u; bool hit = false, clear;
-    if (!cube_fast<true>(P.rect_m, f0.a0, f0.a1, f0.b0, f0.b1, mnz, f0.k, ray, t_min, t_max, t_out, face, hit, clear, room >> 8)) return false;
+    if (!cube_fast<true, SITE>(P.rect_m, f0.a0, f0.a1, f0.b0, f0.b1, mnz, f0.k, ray, t_min, t_max, t_out, face, hit, clear, room >> 8)) return false;
     if (hit) { any = true; prim_out = (G_RECT << 28) | (first + face); }
     return true;
 }
@@ -884,6 +893,17 @@ DEV void object_hit(const KParams<T>& P, uint32_t oi, const DObject& ob, const R
     for (uint32_t k = 0; k < ob.n_ops; k++) op_fwd(ld_op(P.ops + ob.first_op + k), r);
     if (!(FEATS & F_MEDIUM) || ob.medium < 0) {
         T t; uint32_t prim;
+        if constexpr (RoomSite<T, FEATS>::on) {
+            // (the mesh kernels' one site of the Cube fast path: a room or a bare Cube in the world list; an unclear wave takes the plain tests below)
+            if (ob.geom_kind == G_RECT && ob.is_cube != 0u) {
+                bool a = false;
+                t = closest;
+                if (cube_hit<1>(P, ob.geom_first, ob.geom_count, (ob.is_cube & 2u) ? ob.is_cube : 0u, r, t_min, closest, t, prim, a)) {
+                    if (a) { closest = t; id.obj = oi; id.prim = prim; any = true; }
+                    return;
+                }
+            }
+        }
         if (geom_hit<T, FEATS>(P, ob, r, t_min, closest, t, prim, stack, rng, no_sub)) { closest = t; id.obj = oi; id.prim = prim; any = true; }
     } else {
         // ConstantMedium::hit, medium.rs:27-61

@@ -94,7 +94,9 @@ def test_flatten_tables(pbe, earth):
     assert f["rects"] == 400 * 6 + 1 and f["spheres"] == 1000 + 6 - 1 + 1 and f["moving_spheres"] == 1
     assert f["bvh_nodes"] == (2 * 400 - 1) + (2 * 1000 - 1) and f["media"] == 2 and f["perlins"] == 1 and f["objects"] == 11 - 3
     t = R.flatten(build_scene("teapot", pbe)[0])
-    assert t["triangles"] == 1024 and t["bvh_nodes"] == 2047 and t["rects"] == 6
+    # (the teapot room's five walls stand next to each other in the list: one room object in place — the simple form, no second list —, its
+    # run of rect records = copies of the five + two records that carry the box; then the light, then the mesh's BVH)
+    assert t["triangles"] == 1024 and t["bvh_nodes"] == 2047 and t["rects"] == 6 + 5 + 2 and t["objects"] == 3
 
 
 def _objects(pbe, b):
@@ -188,7 +190,31 @@ def test_rooms_are_formed_from_exact_faces_only(pbe):
     t = R.debug_objects(_room_list(pbe, spec))
     assert [(o["geom_count"], o["n_ops"], bool(o["is_cube"] & 2)) for o in t] == [(1, 0, False), (1, 1, False), (4, 0, True)]
     assert [(t[2]["first_op"] >> (5 * j)) & 31 for j in range(4)] == [0, 1, 2, 2]
-    # scenes the list-scene kernels do not serve keep their lists (a sphere: F_SPHERES)
+    # a scene whose only other feature is a BVH of triangles (the mesh kernels) gets a room in the SIMPLE form only: the walls next to each
+    # other, nothing between them — it stands where they stood, no second list; with the lamp between two walls the list stays as it is
+    def mesh_room(lamp_between):
+        bm = SceneBuilder(pbe)
+        mm = bm.Lambertian(bm.ConstantTexture((0.5, 0.5, 0.5)))
+        wl = bm.HittableList()
+        walls = [bm.AARect(YZ, 0.0, 6.0, 0.0, 8.0, 4.0, mm), bm.AARect(YZ, 0.0, 6.0, 0.0, 8.0, 0.0, mm), bm.AARect(XZ, 0.0, 4.0, 0.0, 8.0, 0.0, mm),
+                 bm.AARect(XZ, 0.0, 4.0, 0.0, 8.0, 6.0, mm), bm.AARect(XY, 0.0, 4.0, 0.0, 6.0, 8.0, mm)]
+        lamp = bm.FlipNormal(bm.AARect(XZ, 1.0, 3.0, 1.0, 3.0, 5.9, bm.DiffuseLight(bm.ConstantTexture((4.0, 4.0, 4.0)))))
+        for i, w_ in enumerate(walls):
+            if lamp_between and i == 2:
+                wl.push(lamp)
+            wl.push(w_)
+        if not lamp_between:
+            wl.push(lamp)
+        tris = bm.HittableList()
+        for k in range(4):
+            tris.push(bm.Triangle(((1.0, 1.0 + k, 2.0), (2.0, 1.0 + k, 2.0), (1.5, 1.5 + k, 3.0)), mm))
+        wl.push(bm.BVH(tris, 0.0, 1.0))
+        bm.set_scene(wl, [lamp])
+        return bm
+    t = R.debug_objects(mesh_room(False), top_only=False)
+    assert [(o["geom_kind"], o["geom_count"], bool(o["is_cube"] & 2)) for o in t] == [(0, 5, True), (0, 1, False), (4, 1, False)] and t[0]["first_op"] == 0
+    assert rooms(mesh_room(True)) == []
+    # scenes the list-scene and mesh kernels do not serve keep their lists (a sphere: F_SPHERES)
     b = _room_list(pbe, [("w", XY, True), ("w", XZ, True), ("w", YZ, True), ("w", YZ, False)])
     b2 = SceneBuilder(pbe)
     m = b2.Lambertian(b2.ConstantTexture((0.5, 0.5, 0.5)))

@@ -886,6 +886,68 @@ def test_view_tuned_filter_tree_is_scheduling_only(pbe, monkeypatch):
     assert np.all(np.abs(got - plain.sum(axis=2)) <= 1e-12 * (spp + np.abs(plain.sum(axis=2))))
 
 
+def _walled_mesh_room(be, seed):
+    """A room whose walls ARE faces of one box and stand next to each other in the list (what rt_flatten.cpp's form_room makes ONE object of
+    in a mesh scene: the teapot room's shape, main.rs:416-444), 4 – 5 of them, the lamp behind them, then triangle-mesh BVHs (one under
+    Translate(Rotate)), sometimes a bare Cube: the mesh kernels' single site of the Cube fast path."""
+    rs = np.random.RandomState(300 + seed)
+    b = SceneBuilder(be)
+    mats = [b.Lambertian(b.ConstantTexture(tuple(float(x) for x in rs.uniform(0.1, 0.9, 3)))) for _ in range(3)] + [b.Metal((0.8, 0.85, 0.88), 0.1)]
+    light = b.DiffuseLight(b.ConstantTexture((9.0, 9.0, 8.0)))
+    L = 555.0
+    faces = [(Plane.YZ, L), (Plane.YZ, 0.0), (Plane.XZ, 0.0), (Plane.XZ, L), (Plane.XY, L), (Plane.XY, 0.0)]
+    keep = [faces[i] for i in rs.permutation(6)[: int(rs.choice([4, 5, 5]))]]
+    world = b.HittableList()
+    for plane, k_ in keep:
+        world.push(b.AARect(plane, 0.0, L, 0.0, L, k_, mats[rs.randint(0, 4)]))
+    lamp = b.FlipNormal(b.AARect(Plane.XZ, 128.0, 428.0, 115.0, 270.0, 554.0, light))
+    world.push(lamp)
+
+    def blob(center, radius, n, mat):
+        tris = []
+        for _ in range(n):
+            p0 = center + rs.uniform(-radius, radius, 3)
+            tris.append(b.Triangle([tuple(p0), tuple(p0 + rs.uniform(-30, 30, 3)), tuple(p0 + rs.uniform(-30, 30, 3))], mat))
+        return b.BVH(tris, 0.0, 1.0)
+
+    world.push(blob(np.array([200.0, 140.0, 260.0]), 80.0, int(rs.randint(60, 200)), mats[0]))
+    if rs.rand() < 0.5:
+        world.push(b.Cube((330.0, 0.0, 120.0), (430.0, 160.0, 220.0), mats[1]))
+    world.push(b.Translate(b.Rotate(Axis.Y, blob(np.array([0.0, 0.0, 0.0]), 60.0, int(rs.randint(40, 120)), mats[3]), float(rs.uniform(-40, 40))), (380.0, 260.0, 330.0)))
+    b.set_scene(world, [lamp])
+    frm = [(278.0, 278.0, -800.0), (199.0, 439.0, -200.0), (278.0, 300.0, 40.0), (900.0, 700.0, -600.0)][seed % 4]
+    cam = Camera(frm, (278.0, 250.0, 278.0), (0.0, 1.0, 0.0), 40.0, 1.0, 0.0, 10.0, 0.0, 1.0)
+    return b, cam, (0.02, 0.02, 0.03)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_room_in_a_mesh_scene(pbe, obe, orc_mod, seed, monkeypatch):
+    """The SIMPLE room form (round 6): walls that are faces of one box and stand next to each other in the list of a scene whose only other
+    feature is a BVH of triangles — the teapot room, C4 — are one object where they stood, tested through the Cube fast path at the mesh
+    kernels' world-list site (rt_kernel.hip RoomSite).  Per sample against the oracle, in both loop shapes, and word for word against the
+    same scene flattened without the room (RT_NO_ROOM)."""
+    mk = (lambda be: build_scene("teapot", be)) if seed == 0 else (lambda be: _walled_mesh_room(be, seed))
+    W, H, spp, depth = 64, 48, 8, 30
+    pb, pcam, pbg = mk(pbe)
+    assert any(o["is_cube"] & 2 for o in R.debug_objects(pb)), "no room formed"
+    ob, ocam, obg = mk(obe)
+    _, rs_, cnt = orc_mod.render(ob, ocam, obg, W, H, spp, depth, want_samples=True, want_counters=True)
+    shots = {}
+    for name, flags in (("persistent", R.RT_PERSISTENT_BVH), ("lockstep", R.RT_LOCKSTEP_BVH)):
+        _, gs = R.render(pb, pcam, pbg, W, H, spp, depth, flags=flags, want_samples=True)
+        assert R.last_loop_info(pb)["feats"] in (5, 261)
+        n_bad, _, _ = _compare_samples(gs, rs_)
+        assert n_bad <= MAX_DIVERGED, f"{name}: {n_bad} of {W * H * spp} samples diverged"
+        assert R.last_stats(pb)["nonfinite_samples"] == cnt["nonfinite"]
+        shots[name] = gs
+    assert np.array_equal(shots["persistent"].view(np.uint64), shots["lockstep"].view(np.uint64))
+    monkeypatch.setenv("RT_NO_ROOM", "1")
+    qb, qcam, qbg = mk(pbe)
+    assert not any(o["is_cube"] & 2 for o in R.debug_objects(qb))
+    _, plain = R.render(qb, qcam, qbg, W, H, spp, depth, flags=R.RT_LOCKSTEP_BVH, want_samples=True)
+    assert np.array_equal(plain.view(np.uint64), shots["lockstep"].view(np.uint64)), "the room form changed a sample"
+
+
 def _big_mesh_room(be, n_tris):
     rs = np.random.RandomState(5)
     b = SceneBuilder(be)
