@@ -281,7 +281,9 @@ int rt_debug_tune_filter(rt_scene*, const rt_camera*);
  * object, as hit.rs:62-68 gives it to the later item; rt_flatten.cpp form_room), nest (sub-objects: wrapper ops outside the enclosing BVH | ops outside the medium << 8; bit 16:
  * every wrapper is a FlipNormal)}: the
  * world's top-level objects (HittableList push order,
- * runs of bare primitives merged) first — *n_top_out of them — then the sub-objects BVH leaves of other Hittable kinds refer to.
+ * runs of bare primitives merged) first — *n_top_out of them — then the sub-objects BVH leaves of other Hittable kinds refer to, or — a list
+ * scene in which a room was formed — the world list as the reference has it (what a wave searches when one of its rays could produce a NaN
+ * plane distance, rt_kernel.hip world_hit_list).
  * Returns the number of objects or -1. */
 int rt_debug_objects(rt_scene*, uint32_t* out, uint32_t max_objects, uint32_t* n_top_out);
 /* Test aid (host only, no GPU): the flattened BVH's link words, out[4*i..] = node i's {a, b, c, skip}: `a` bit 31 marks a leaf (then kind
