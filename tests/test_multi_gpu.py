@@ -120,7 +120,7 @@ def test_render_multi_failure_leaves_nothing_behind(pbe, monkeypatch):
     dev_before = torch.cuda.current_device()
     free0 = torch.cuda.mem_get_info()[0]
     monkeypatch.setenv("RT_MULTI_FAIL_RANK", "2")
-    for _ in range(10):
+    for _ in range(30):
         with pytest.raises(R.RenderError, match="rank 2.*injected failure"):
             R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
         with pytest.raises(R.RenderError, match="injected failure"):
@@ -128,7 +128,9 @@ def test_render_multi_failure_leaves_nothing_behind(pbe, monkeypatch):
     R.multi_sync(b)                                      # nothing pending: returns at once
     torch.cuda.synchronize()
     assert torch.cuda.current_device() == dev_before
-    assert torch.cuda.mem_get_info()[0] >= free0 - (1 << 20)
+    # (sixty failing calls: one leaked tile buffer per call would be tens of megabytes; the HIP runtime's own pools grow in 2 MiB steps at
+    # moments of their choosing — one such step inside this window failed the test once at a tolerance of 1 MiB)
+    assert torch.cuda.mem_get_info()[0] >= free0 - (4 << 20)
     monkeypatch.delenv("RT_MULTI_FAIL_RANK")
     again = R.render_multi(b, cam, bg, W, H, spp, depth, device_mask=1)
     assert np.array_equal(again, good) and np.all(np.abs(again - ref) <= 1e-12 * (spp + np.abs(ref)))
