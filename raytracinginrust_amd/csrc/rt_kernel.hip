@@ -413,7 +413,8 @@ template <typename T, uint32_t FEATS> struct CubeFast { static constexpr bool on
 // for rooms (round 6: their five walls stand next to each other in the list, nothing between them, so the room stands exactly where they
 // stood: no tie rule, no second list) and bare Cubes; their BVH leaves hold triangles and keep the plain code (*measured* round 5: the
 // fast path compiled into the leaf tests costs these kernels 1 % and serves nothing there).
-template <typename T, uint32_t FEATS> struct RoomSite { static constexpr bool on = sizeof(T) == 8u && (FEATS & ~(uint32_t)(F_PERSIST | F_NEAR_FIRST)) == (uint32_t)(F_BVH | F_TRIS); };
+// (the persistent-traversal ones: *measured* teapot room +1.6 %; the lock-step mesh kernels -0.7 % with it — they serve a room by its walls' exact tests)
+template <typename T, uint32_t FEATS> struct RoomSite { static constexpr bool on = sizeof(T) == 8u && (FEATS & ~(uint32_t)F_NEAR_FIRST) == (uint32_t)(F_BVH | F_TRIS | F_PERSIST); };
 template <int SITE = 0>
 DEV bool cube_hit(const KParams<double>& P, uint32_t first, uint32_t count, uint32_t room, const RayT<double>& ray, double t_min, double t_max, double& t_out, uint32_t& prim_out, bool& any) {
     const uint32_t box_at = room != 0u ? first + count : first;
